@@ -1,0 +1,345 @@
+"""CPU oracle for the log-mel front-ends.  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module; the product package never does.
+
+PARITY UNPINNED for every function in this file: the reference holds no
+front-end arithmetic and no tests of its own.  Each flavour below calls into a
+third-party package that is neither vendored in the reference nor installed
+here, so this file restates those packages' published algorithms and anchors
+them on the reference's call sites:
+
+  F1/F2  torchlibrosa==0.0.9  Spectrogram / LogmelFilterBank
+         call site external/hts_audio_transformer/model/htsat.py:443-459,763-764
+         (mel matrix: librosa.filters.mel, librosa<=0.11.0)
+  F3     TF-Hub google/yamnet/1 (tensorflow/models research/audioset/yamnet
+         params.py / features.py / yamnet.py:pad_waveform)
+         call sites src/models/yamnet_train.py:46-47,
+         src/models/single_stage_yamnet_frame.py:64-65
+  F4     librosa.feature.melspectrogram(power=1.0) + np.log(S + 1e-9)
+         call site src/models/crnn/process_audio.py:29-34
+  F5     librosa.feature.melspectrogram(power=2.0) + power_to_db(ref=np.max)
+         call site src/utils/audio_to_spectrograms.py:30-44
+
+Two evaluation modes per flavour:
+  * gold  : fp64 arithmetic on the fp32 tables the reference would hold
+            (window, mel matrix) -- the yardstick for the 1e-3 tolerance.
+  * ref32 : the reference's own fp32 formulation (fp32 windowed-DFT matrix as
+            conv weights, fp32 matmul, fp32 log) -- used for the deep-bin
+            criterion and as the CPU baseline.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+# ----------------------------------------------------------------------------
+# tables
+# ----------------------------------------------------------------------------
+
+
+def hann_periodic(win_length: int) -> np.ndarray:
+    """scipy.signal.get_window('hann', N, fftbins=True) in fp64."""
+    n = np.arange(win_length, dtype=np.float64)
+    return 0.5 - 0.5 * np.cos(2.0 * np.pi * n / win_length)
+
+
+def pad_center(w: np.ndarray, size: int) -> np.ndarray:
+    """librosa.util.pad_center: zero-pad symmetrically (left = (size-n)//2)."""
+    n = w.shape[0]
+    lpad = (size - n) // 2
+    out = np.zeros(size, dtype=w.dtype)
+    out[lpad:lpad + n] = w
+    return out
+
+
+def hz_to_mel_slaney(f):
+    f = np.asarray(f, dtype=np.float64)
+    f_sp = 200.0 / 3
+    mels = f / f_sp
+    min_log_hz = 1000.0
+    min_log_mel = min_log_hz / f_sp
+    logstep = np.log(6.4) / 27.0
+    with np.errstate(divide="ignore", invalid="ignore"):
+        logpart = min_log_mel + np.log(np.maximum(f, 1e-300) / min_log_hz) / logstep
+    return np.where(f >= min_log_hz, logpart, mels)
+
+
+def mel_to_hz_slaney(m):
+    m = np.asarray(m, dtype=np.float64)
+    f_sp = 200.0 / 3
+    freqs = f_sp * m
+    min_log_hz = 1000.0
+    min_log_mel = min_log_hz / f_sp
+    logstep = np.log(6.4) / 27.0
+    return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), freqs)
+
+
+def librosa_mel(sr, n_fft, n_mels=128, fmin=0.0, fmax=None) -> np.ndarray:
+    """librosa.filters.mel(htk=False, norm='slaney') -> (n_mels, 1+n_fft//2) fp32."""
+    if fmax is None:
+        fmax = float(sr) / 2
+    n_bins = 1 + n_fft // 2
+    fftfreqs = np.linspace(0.0, float(sr) / 2, n_bins)  # == rfftfreq
+    mel_pts = np.linspace(hz_to_mel_slaney(fmin), hz_to_mel_slaney(fmax), n_mels + 2)
+    mel_f = mel_to_hz_slaney(mel_pts)
+    fdiff = np.diff(mel_f)
+    ramps = mel_f[:, None] - fftfreqs[None, :]
+    weights = np.zeros((n_mels, n_bins), dtype=np.float64)
+    for i in range(n_mels):
+        lower = -ramps[i] / fdiff[i]
+        upper = ramps[i + 2] / fdiff[i + 1]
+        weights[i] = np.maximum(0.0, np.minimum(lower, upper))
+    enorm = 2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels])
+    weights *= enorm[:, None]
+    return weights.astype(np.float32)
+
+
+def tf_linear_to_mel_weight_matrix(num_mel_bins=64, num_spectrogram_bins=257, sample_rate=16000,
+                                   lower_edge_hertz=125.0, upper_edge_hertz=7500.0) -> np.ndarray:
+    """tf.signal.linear_to_mel_weight_matrix -> (num_spectrogram_bins, num_mel_bins) fp32.
+
+    HTK mel 1127*ln(1+f/700); triangles linear in mel, peak 1, no area norm, DC row zero.
+    Evaluated in fp64 and rounded once to fp32 (TF evaluates the same expressions in fp32).
+    """
+    def hz_to_mel(f):
+        return 1127.0 * np.log1p(np.asarray(f, dtype=np.float64) / 700.0)
+
+    nyquist = sample_rate / 2.0
+    lin = np.linspace(0.0, nyquist, num_spectrogram_bins)[1:]
+    spec_mel = hz_to_mel(lin)[:, None]
+    edges = np.linspace(hz_to_mel(lower_edge_hertz), hz_to_mel(upper_edge_hertz), num_mel_bins + 2)
+    lower, center, upper = edges[:-2][None, :], edges[1:-1][None, :], edges[2:][None, :]
+    lower_slopes = (spec_mel - lower) / (center - lower)
+    upper_slopes = (upper - spec_mel) / (upper - center)
+    w = np.maximum(0.0, np.minimum(lower_slopes, upper_slopes))
+    w = np.pad(w, [[1, 0], [0, 0]])
+    return w.astype(np.float32)
+
+
+# ----------------------------------------------------------------------------
+# framing
+# ----------------------------------------------------------------------------
+
+
+def _frames(y: np.ndarray, n_fft: int, hop: int, n_frames: int) -> np.ndarray:
+    """(..., L) -> (..., n_frames, n_fft) strided view copy."""
+    idx = np.arange(n_fft)[None, :] + hop * np.arange(n_frames)[:, None]
+    return y[..., idx]
+
+
+def _pad_signal(x: np.ndarray, pad: int, mode: str) -> np.ndarray:
+    if pad == 0:
+        return x
+    widths = [(0, 0)] * (x.ndim - 1) + [(pad, pad)]
+    if mode == "reflect":
+        return np.pad(x, widths, mode="reflect")
+    if mode == "constant":
+        return np.pad(x, widths, mode="constant")
+    raise ValueError(mode)
+
+
+def stft_frames(x: np.ndarray, n_fft: int, hop: int, center: bool, pad_mode: str):
+    """Padded+framed signal in the dtype of x. T = 1 + (L_padded - n_fft)//hop."""
+    xp = _pad_signal(x, n_fft // 2, pad_mode) if center else x
+    n_frames = 1 + (xp.shape[-1] - n_fft) // hop
+    return _frames(xp, n_fft, hop, n_frames)
+
+
+def windowed_dft_matrix(n_fft: int, window_full: np.ndarray):
+    """torchlibrosa STFT conv weights: Re/Im(exp(-2*pi*i*n*k/n_fft)) * window[n], (n_fft, F) fp64.
+
+    torchlibrosa builds W = exp(-2 pi i x y / n) via np.power(omega, x*y); evaluated here through the
+    exact angle reduction (n*k mod n_fft) which is what that expression equals mathematically.
+    """
+    n = np.arange(n_fft)[:, None]
+    k = np.arange(n_fft // 2 + 1)[None, :]
+    ang = -2.0 * np.pi * ((n * k) % n_fft) / n_fft
+    return np.cos(ang) * window_full[:, None], np.sin(ang) * window_full[:, None]
+
+
+def power_spectrogram_gold(x, n_fft, hop, win_length=None, center=True, pad_mode="reflect",
+                           window_full=None):
+    """fp64 |STFT|^2, (..., T, F), with the exact fp64 window."""
+    if window_full is None:
+        win_length = n_fft if win_length is None else win_length
+        window_full = pad_center(hann_periodic(win_length), n_fft)
+    fr = stft_frames(np.asarray(x, dtype=np.float64), n_fft, hop, center, pad_mode)
+    spec = np.fft.rfft(fr * window_full.astype(np.float64), n=n_fft, axis=-1)
+    return spec.real ** 2 + spec.imag ** 2
+
+
+def power_spectrogram_ref32(x, n_fft, hop, win_length=None, center=True, pad_mode="reflect",
+                            window_full=None):
+    """fp32 conv-DFT formulation (two real matmuls with fp32 weights), (..., T, F) fp32."""
+    if window_full is None:
+        win_length = n_fft if win_length is None else win_length
+        window_full = pad_center(hann_periodic(win_length), n_fft)
+    wr, wi = windowed_dft_matrix(n_fft, window_full)
+    wr = wr.astype(np.float32)
+    wi = wi.astype(np.float32)
+    fr = stft_frames(np.asarray(x, dtype=np.float32), n_fft, hop, center, pad_mode)
+    re = fr @ wr
+    im = fr @ wi
+    return re * re + im * im
+
+
+# ----------------------------------------------------------------------------
+# F1 + F2 : torchlibrosa Spectrogram + LogmelFilterBank (HTS-AT)
+# ----------------------------------------------------------------------------
+
+
+def power_to_db(x, ref=1.0, amin=1e-10, top_db=None):
+    """torchlibrosa LogmelFilterBank.power_to_db: top_db clamps against the GLOBAL max of the tensor."""
+    dt = x.dtype
+    log_spec = 10.0 * np.log10(np.maximum(x, dt.type(amin)))
+    log_spec = log_spec - dt.type(10.0 * np.log10(np.maximum(amin, ref)))
+    if top_db is not None:
+        log_spec = np.maximum(log_spec, log_spec.max() - dt.type(top_db))
+    return log_spec.astype(dt)
+
+
+def htsat_logmel(x, sr=32000, n_fft=1024, hop=320, n_mels=64, fmin=50, fmax=14000,
+                 ref=1.0, amin=1e-10, top_db=None, mode="gold"):
+    """(B, L) -> (B, 1, T, n_mels). mode 'gold' = fp64, 'ref32' = fp32 reference formulation."""
+    melW = librosa_mel(sr, n_fft, n_mels, fmin, fmax).T  # (F, M) fp32
+    if mode == "gold":
+        p = power_spectrogram_gold(x, n_fft, hop, center=True, pad_mode="reflect")
+        mel = p @ melW.astype(np.float64)
+    else:
+        p = power_spectrogram_ref32(x, n_fft, hop, center=True, pad_mode="reflect")
+        mel = p @ melW
+    out = power_to_db(mel, ref, amin, top_db)
+    return out[:, None, :, :]
+
+
+# ----------------------------------------------------------------------------
+# F3 : YAMNet features
+# ----------------------------------------------------------------------------
+
+YAMNET = dict(sample_rate=16000, win=400, hop=160, n_fft=512, n_mels=64, fmin=125.0, fmax=7500.0,
+              log_offset=0.001, patch_frames=96, patch_hop=48,
+              min_samples=15600, hop_samples=7680)
+
+
+def yamnet_padded_length(L: int) -> int:
+    p = YAMNET
+    n = max(L, p["min_samples"])
+    after = n - p["min_samples"]
+    hops = int(math.ceil(np.float32(after) / np.float32(p["hop_samples"])))
+    return p["min_samples"] + p["hop_samples"] * hops
+
+
+def yamnet_logmel(x, mode="gold"):
+    """(B, L) or (L,) fp32 in [-1,1] -> (log_mel (B,T,64), patches (B,N,96,64))."""
+    p = YAMNET
+    x = np.atleast_2d(np.asarray(x))
+    L = x.shape[-1]
+    Lp = yamnet_padded_length(L)
+    dt = np.float64 if mode == "gold" else np.float32
+    xp = np.zeros(x.shape[:-1] + (Lp,), dtype=dt)
+    xp[..., :L] = x
+    T = 1 + (Lp - p["win"]) // p["hop"]
+    idx = np.arange(p["win"])[None, :] + p["hop"] * np.arange(T)[:, None]
+    w = hann_periodic(p["win"]).astype(np.float32)
+    melW = tf_linear_to_mel_weight_matrix(p["n_mels"], p["n_fft"] // 2 + 1, p["sample_rate"], p["fmin"], p["fmax"])
+    if mode == "gold":
+        fr = xp[..., idx] * w.astype(np.float64)
+        mag = np.abs(np.fft.rfft(fr, n=p["n_fft"], axis=-1))
+        mel = mag @ melW.astype(np.float64)
+        log_mel = np.log(mel + p["log_offset"])
+    else:
+        wfull = np.zeros(p["n_fft"]); wfull[:p["win"]] = w
+        wr, wi = windowed_dft_matrix(p["n_fft"], wfull)
+        fr = np.zeros(xp.shape[:-1] + (T, p["n_fft"]), dtype=np.float32)
+        fr[..., :p["win"]] = xp[..., idx]
+        re = fr @ wr.astype(np.float32); im = fr @ wi.astype(np.float32)
+        mag = np.sqrt(re * re + im * im)
+        mel = mag @ melW
+        log_mel = np.log(mel + np.float32(p["log_offset"]))
+    N = 1 + (T - p["patch_frames"]) // p["patch_hop"]
+    pidx = np.arange(p["patch_frames"])[None, :] + p["patch_hop"] * np.arange(N)[:, None]
+    patches = log_mel[..., pidx, :]
+    return log_mel, patches
+
+
+# ----------------------------------------------------------------------------
+# F4 : CRNN log mel-band energy ; F5 : librosa dB mel
+# ----------------------------------------------------------------------------
+
+
+def crnn_extract_mbe(y, sr=44100, n_fft=2048, n_mels=40, hop=1024, mode="gold", pad_mode="constant"):
+    """(L,) or (B, L) -> (n_mels, T) / (B, n_mels, T): ln(mel(|STFT|) + 1e-9). librosa>=0.10 pads with zeros."""
+    melW = librosa_mel(sr, n_fft, n_mels, 0.0, sr / 2.0)  # (M, F)
+    if mode == "gold":
+        p = power_spectrogram_gold(y, n_fft, hop, center=True, pad_mode=pad_mode)
+        mel = np.sqrt(p) @ melW.T.astype(np.float64)
+        out = np.log(mel + 1e-9)
+    else:
+        p = power_spectrogram_ref32(y, n_fft, hop, center=True, pad_mode=pad_mode)
+        mel = np.sqrt(p) @ melW.T
+        out = np.log(mel + np.float32(1e-9))
+    return np.swapaxes(out, -1, -2)
+
+
+def librosa_db_mel(y, sr=44100, n_fft=2048, hop=512, n_mels=64, mode="gold", pad_mode="constant",
+                   amin=1e-10, top_db=80.0):
+    """get_mel_spec: power mel -> power_to_db(ref=np.max) with the per-clip max and an 80 dB floor. (n_mels, T)."""
+    melW = librosa_mel(sr, n_fft, n_mels, 0.0, float(sr // 2))
+    if mode == "gold":
+        p = power_spectrogram_gold(y, n_fft, hop, center=True, pad_mode=pad_mode)
+        mel = p @ melW.T.astype(np.float64)
+    else:
+        p = power_spectrogram_ref32(y, n_fft, hop, center=True, pad_mode=pad_mode)
+        mel = p @ melW.T
+    dt = mel.dtype
+    ref = mel.max(axis=(-1, -2), keepdims=True)
+    log_spec = 10.0 * np.log10(np.maximum(dt.type(amin), mel))
+    log_spec = log_spec - 10.0 * np.log10(np.maximum(dt.type(amin), ref))
+    log_spec = np.maximum(log_spec, log_spec.max(axis=(-1, -2), keepdims=True) - dt.type(top_db))
+    return np.swapaxes(log_spec.astype(dt), -1, -2)
+
+
+# ----------------------------------------------------------------------------
+# synthetic audio (seeded; the value distribution the parity tests and the bench use)
+# ----------------------------------------------------------------------------
+
+
+def synth_clip(clip_idx: int, n_samples: int, sr: int) -> np.ndarray:
+    """Pink-ish noise + two sine bursts + 0.5 s of exact digital silence. fp32 in [-1, 1]."""
+    rng = np.random.default_rng(1234 + clip_idx)
+    white = rng.standard_normal(n_samples)
+    pink = np.cumsum(white)
+    pink -= np.linspace(pink[0], pink[-1], n_samples)
+    pink = pink / (np.abs(pink).max() + 1e-12) * 0.5
+    x = pink + 0.1 * 0.1 * white
+    t = np.arange(n_samples) / sr
+    for _ in range(2):
+        f = rng.uniform(200.0, 6000.0)
+        dur = rng.uniform(0.3, min(3.0, n_samples / sr * 0.5))
+        start = rng.uniform(0.0, max(1e-3, n_samples / sr - dur))
+        amp = rng.uniform(0.05, 0.5)
+        m = (t >= start) & (t < start + dur)
+        x[m] += amp * np.sin(2 * np.pi * f * t[m])
+    x = np.clip(x, -1.0, 1.0)
+    sil = int(0.5 * sr)
+    if n_samples > 2 * sil:
+        s0 = int(rng.integers(0, n_samples - sil))
+        x[s0:s0 + sil] = 0.0
+    return x.astype(np.float32)
+
+
+def synth_batch(n_clips: int, n_samples: int, sr: int, first: int = 0) -> np.ndarray:
+    return np.stack([synth_clip(first + i, n_samples, sr) for i in range(n_clips)])
+
+
+def pcm16_to_f32(x: np.ndarray) -> np.ndarray:
+    """int16 PCM -> fp32 by the HTS-AT convention (divide by 32767 in fp64, round once to fp32),
+    external/hts_audio_transformer/utils.py:96-97."""
+    return np.asarray(np.asarray(x, dtype=np.float64) / 32767.0, dtype=np.float32)
+
+
+def f32_to_pcm16(x: np.ndarray) -> np.ndarray:
+    """fp32 in [-1,1] -> int16 (clip, scale by 32767, truncate), external/hts_audio_transformer/utils.py:99-101."""
+    return np.asarray(np.clip(x, -1.0, 1.0) * 32767.0, dtype=np.int16)

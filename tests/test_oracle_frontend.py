@@ -1,0 +1,68 @@
+"""The front-end oracle: shapes, floors, and a cross-check against torch.stft (independent implementation)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import frontend as of
+
+
+def test_mel_matrix_htsat_structure():
+    w = of.librosa_mel(32000, 1024, 64, 50, 14000)
+    assert w.shape == (64, 513) and w.dtype == np.float32
+    assert int((w != 0).sum()) == 866
+    nz = [np.flatnonzero(r) for r in w]
+    assert all(np.all(np.diff(i) == 1) for i in nz)            # every filter is one contiguous band
+    assert all(nz[i][0] <= nz[i + 1][0] for i in range(63))
+
+
+def test_mel_matrix_tf_structure():
+    w = of.tf_linear_to_mel_weight_matrix()
+    assert w.shape == (257, 64) and np.all(w[0] == 0) and w.max() <= 1.0
+    assert np.all(w.sum(axis=0) > 0)
+
+
+@pytest.mark.parametrize("n_fft,hop,center,mode", [(1024, 320, True, "reflect"), (2048, 1024, True, "constant"),
+                                                    (512, 160, False, "reflect")])
+def test_power_spectrogram_vs_torch_stft(n_fft, hop, center, mode):
+    x = of.synth_batch(2, 16000, 16000)
+    got = of.power_spectrogram_gold(x, n_fft, hop, center=center, pad_mode=mode)
+    win = torch.hann_window(n_fft, periodic=True, dtype=torch.float64)
+    s = torch.stft(torch.from_numpy(x).double(), n_fft, hop, n_fft, win, center=center, pad_mode=mode,
+                   return_complex=True)
+    want = (s.abs() ** 2).transpose(1, 2).numpy()
+    assert got.shape == want.shape
+    assert np.max(np.abs(got - want)) <= 1e-9 * max(1.0, want.max())
+    r32 = of.power_spectrogram_ref32(x, n_fft, hop, center=center, pad_mode=mode)
+    assert np.max(np.abs(r32 - want)) <= 2e-5 * want.max()
+
+
+def test_shapes_and_floors():
+    x = np.zeros((2, 320000), np.float32)
+    y = of.htsat_logmel(x, mode="ref32")
+    assert y.shape == (2, 1, 1001, 64) and np.all(y == y.flat[0]) and abs(float(y.flat[0]) + 100.0) < 2e-5
+    lm, patches = of.yamnet_logmel(np.zeros((1, 160000), np.float32), mode="ref32")
+    assert lm.shape == (1, 1008, 64) and patches.shape == (1, 20, 96, 64)
+    assert np.all(lm == np.log(np.float32(0.001)))
+    assert of.yamnet_padded_length(320000) == 322800
+    lm20, p20 = of.yamnet_logmel(np.zeros((1, 320000), np.float32), mode="ref32")
+    assert lm20.shape[1] == 2016 and p20.shape[1] == 41
+    m = of.crnn_extract_mbe(np.zeros(882000, np.float32), mode="ref32")
+    assert m.shape == (40, 862) and np.all(m == np.log(np.float32(1e-9)))
+    d = of.librosa_db_mel(of.synth_clip(0, 44100, 44100), mode="ref32")
+    assert d.shape == (64, 1 + 44100 // 512) and d.max() == 0.0 and d.min() >= -80.0
+
+
+def test_gold_vs_ref32_tolerance_broadband():
+    x = of.synth_batch(2, 32000, 32000)
+    g = of.htsat_logmel(x, mode="gold")
+    r = of.htsat_logmel(x, mode="ref32")
+    peak = g.max(axis=-1, keepdims=True)
+    near = g >= peak - 60.0
+    assert np.max(np.abs(g - r)[near]) < 1e-3
+
+
+def test_pcm16_convention():
+    s = np.arange(-32768, 32768, dtype=np.int16)
+    f = of.pcm16_to_f32(s)
+    assert f.dtype == np.float32
+    assert np.array_equal(f, (s.astype(np.float32) / np.float32(32767.0)))   # fp32 division gives the same bits
