@@ -1,0 +1,189 @@
+/*
+ * sed_hip.h -- C ABI of libsedhip.so: hand-written HIP (gfx950) kernels for the batched log-mel
+ * front-end and the frame-level event decoders of a sound-event-detection pipeline.
+ *
+ * Plain pointers and sizes only.  Unless stated otherwise every data pointer is a DEVICE pointer on
+ * the device that was current when the plan was created, every call is asynchronous on `stream`
+ * (a hipStream_t passed as void*), performs no allocation and no host synchronisation, and returns
+ * 0 on success or a negative sed_status.  Plans are immutable after creation/set_* and may be shared
+ * across host threads; one in-flight call per (plan, stream).
+ *
+ * Each entry point names the reference interface it replaces (paths relative to the reference root).
+ */
+#ifndef SED_HIP_H_
+#define SED_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum sed_status {
+  SED_OK = 0,
+  SED_ERR_BAD_ARG = -1,          /* null pointer, negative size, inconsistent configuration      */
+  SED_ERR_UNSUPPORTED_NFFT = -2, /* n_fft not in {512, 1024, 2048}                                */
+  SED_ERR_CAPACITY = -3,         /* a fixed-capacity output would overflow                        */
+  SED_ERR_SHORT_INPUT = -4,      /* reflect padding needs L > n_fft/2                             */
+  SED_ERR_WRONG_DEVICE = -5,     /* current device differs from the plan's device                 */
+  SED_ERR_HIP = -1000            /* -(1000 + hipError_t) for HIP runtime failures                 */
+} sed_status;
+
+enum { SED_PAD_NONE = 0, SED_PAD_CONSTANT = 1, SED_PAD_REFLECT = 2 };     /* centre padding mode   */
+enum { SED_SPEC_MAGNITUDE = 1, SED_SPEC_POWER = 2 };
+enum { SED_MEL_SLANEY = 0, SED_MEL_HTK_TF = 1 };
+enum { SED_LOG_NONE = 0, SED_LOG_DB10 = 1, SED_LOG_LN = 2 };
+enum { SED_PCM_F32 = 0, SED_PCM_I16 = 1 };
+enum { SED_WIN_CENTER = 0, SED_WIN_LEFT = 1 };
+enum { SED_SMOOTH_NONE = 0, SED_SMOOTH_MEDIAN3 = 1, SED_SMOOTH_GAUSS25 = 2 };
+
+/*
+ * One front-end flavour.  The four the reference uses:
+ *   HTS-AT  (external/hts_audio_transformer/model/htsat.py:443-459): 32000/1024/1024/320, center, REFLECT,
+ *           POWER, SLANEY 64 mel 50..14000, DB10(amin 1e-10, ref 1, top_db none), WIN_CENTER
+ *   YAMNet  (src/models/yamnet_train.py:46-47): 16000/512/400/160, no centring, MAGNITUDE, HTK_TF 64 mel
+ *           125..7500, LN(0.001), WIN_LEFT, tail_min_samples 15600, tail_hop_samples 7680
+ *   CRNN    (src/models/crnn/process_audio.py:29-34): 44100/2048/2048/1024, center, CONSTANT, MAGNITUDE,
+ *           SLANEY 40 mel 0..22050, LN(1e-9)
+ *   dB mel  (src/utils/audio_to_spectrograms.py:30-44): 44100/2048/2048/512, center, CONSTANT, POWER,
+ *           SLANEY 64 mel 0..22050, DB10 then sed_db_normalize(per clip, top_db 80)
+ */
+typedef struct sed_frontend_cfg {
+  int32_t sample_rate;
+  int32_t n_fft;            /* 512, 1024 or 2048                                                   */
+  int32_t win_length;       /* <= n_fft; periodic Hann                                             */
+  int32_t hop;
+  int32_t center;           /* 1: pad n_fft/2 both sides with pad_mode; T = 1 + L/hop              */
+  int32_t pad_mode;         /* SED_PAD_* (used when center)                                        */
+  int32_t win_align;        /* SED_WIN_CENTER (librosa pad_center) or SED_WIN_LEFT (tf.signal.stft) */
+  int32_t tail_min_samples; /* >0: zero-pad the tail to tail_min + tail_hop*ceil((L-tail_min)/tail_hop) */
+  int32_t tail_hop_samples;
+  int32_t spectrum;         /* SED_SPEC_*                                                          */
+  int32_t mel_kind;         /* SED_MEL_*                                                           */
+  int32_t n_mels;           /* 1..128                                                              */
+  float fmin, fmax;
+  int32_t log_kind;         /* SED_LOG_*                                                           */
+  float amin, ref;          /* DB10: 10*log10(max(x, amin)) - 10*log10(max(amin, ref))             */
+  float ln_offset;          /* LN: ln(x + ln_offset)                                               */
+  int32_t pcm_kind;         /* SED_PCM_*                                                           */
+  float pcm_divisor;        /* I16: sample / pcm_divisor (32767 or 32768)                          */
+} sed_frontend_cfg;
+
+typedef struct sed_plan sed_plan;
+
+const char* sed_version(void);
+
+/* Human-readable text for a status returned by any entry point (static storage). */
+const char* sed_status_string(int status);
+
+/* ---- host-only table builders (no device needed) ------------------------------------------------- */
+
+/* Mel filterbank as the reference modules hold it: melW[k*n_mels + m], k = 0..n_fft/2.
+ * SED_MEL_SLANEY = librosa.filters.mel(htk=False, norm='slaney').T, the buffer logmel_extractor.melW built at
+ * external/hts_audio_transformer/model/htsat.py:457; SED_MEL_HTK_TF = tf.signal.linear_to_mel_weight_matrix
+ * (the YAMNet graph behind src/models/yamnet_train.py:47).  fp64 arithmetic, rounded once to fp32. */
+int sed_mel_filterbank(int32_t mel_kind, int32_t sample_rate, int32_t n_fft, int32_t n_mels, float fmin, float fmax,
+                       float* melW_host);
+
+/* Periodic Hann of win_length inside n_fft samples (centred or left aligned), fp32 [n_fft]. */
+int sed_hann_window(int32_t n_fft, int32_t win_length, int32_t win_align, float* window_host);
+
+/* ---- plans (host side; tables are built in fp64 on the host and uploaded once) ---------------------- */
+
+/* Replaces the constructors torchlibrosa.stft.Spectrogram(...) + LogmelFilterBank(...) as called at
+ * external/hts_audio_transformer/model/htsat.py:453-459 (and the equivalent constant set-up inside
+ * librosa.feature.melspectrogram / the YAMNet graph for the other flavours). */
+int sed_plan_create(const sed_frontend_cfg* cfg, sed_plan** out);
+void sed_plan_destroy(sed_plan* plan);
+
+/* Number of STFT frames for L samples per clip (T of the output), or a negative sed_status. */
+int64_t sed_plan_num_frames(const sed_plan* plan, int64_t n_samples);
+
+/* Pure host helpers: the tables a state_dict of the reference module holds
+ * (logmel_extractor.melW (F, n_mels); the full-length window).  Host pointers. */
+int sed_plan_get_mel_weights(const sed_plan* plan, float* melW_host /* [n_fft/2+1][n_mels] */);
+int sed_plan_get_window(const sed_plan* plan, float* window_host /* [n_fft] */);
+/* Replace the mel matrix (e.g. the one found in a loaded checkpoint).  Host pointer. */
+int sed_plan_set_mel_weights(sed_plan* plan, const float* melW_host /* [n_fft/2+1][n_mels] */);
+/* Per-mel affine epilogue out = x*scale[m] + shift[m]: eval-mode bn0 (htsat.py:463,767-769) or the
+ * CRNN StandardScaler (src/models/crnn/process_audio.py:271-279).  Host pointers; NULL,NULL disables. */
+int sed_plan_set_affine(sed_plan* plan, const float* scale_host, const float* shift_host);
+
+/* ---- front-end kernels ----------------------------------------------------------------------------- */
+
+/* Fused framing + window + real FFT + power/magnitude + mel + log (+ affine).
+ * Replaces logmel_extractor(spectrogram_extractor(x)) at htsat.py:763-764, the features inside
+ * yamnet_model(audio) (yamnet_train.py:47), extract_mbe (crnn/process_audio.py:29-34).
+ * pcm: [B] clips of L samples (fp32 or int16 per the plan), clip b at pcm + b*pcm_stride elements.
+ * out: fp32, frame t of clip b at out + b*out_stride_b + t*n_mels. */
+int sed_logmel_forward(const sed_plan* plan, const void* pcm, int64_t B, int64_t L, int64_t pcm_stride,
+                       float* out, int64_t out_stride_b, void* stream);
+
+/* Unfused parity path: |STFT|^2 (or |STFT|), replaces spectrogram_extractor(x) at htsat.py:763.
+ * out: fp32 [B][T][n_fft/2+1], clip b at out + b*out_stride_b. */
+int sed_spectrogram_forward(const sed_plan* plan, const void* pcm, int64_t B, int64_t L, int64_t pcm_stride,
+                            float* out, int64_t out_stride_b, void* stream);
+
+/* mel projection + log of an already materialised spectrogram: replaces logmel_extractor(x) at htsat.py:764.
+ * spec: fp32 [rows][n_fft/2+1] contiguous; out: fp32 [rows][n_mels]. */
+int sed_mel_from_spectrogram(const sed_plan* plan, const float* spec, int64_t rows, float* out, void* stream);
+
+/* In-place dB post-pass over `groups` contiguous groups of `group_elems` floats: x -= max(group) when
+ * subtract_max, then x = max(x, max(group) - top_db) when top_db >= 0.  librosa.power_to_db(ref=np.max,
+ * top_db=80) per clip (audio_to_spectrograms.py:43) and torchlibrosa's top_db over the whole tensor. */
+int sed_db_normalize(float* x, int64_t groups, int64_t group_elems, int32_t subtract_max, float top_db,
+                     void* stream);
+
+/* ---- decoders -------------------------------------------------------------------------------------- */
+
+/* Smoothing along time + strict threshold + run extraction for every (clip, class) trace.
+ * Replaces gaussian_filter1d + `> posterior_thresh` + find_contiguous_regions
+ * (src/models/crnn/crnn.py:418-425, src/models/crnn/utils.py:77-89) and median_filter + `> threshold` + diff
+ * (src/models/yamnet_train.py:57-66).
+ * probs fp32 [B][T][C]; runs int32 [B][C][cap][2] = (first active frame, one past last active frame) in
+ * ascending order; counts int32 [B][C] = number of runs found (may exceed cap: only the first cap are
+ * stored, the caller checks).  GAUSS25 is evaluated in fp64 in scipy's summation order and rounded to
+ * fp32 before the compare, so the activity equals scipy's bit for bit. */
+int sed_threshold_runs(const float* probs, int64_t B, int64_t T, int64_t C, float threshold, int32_t smoothing,
+                       int32_t* runs, int32_t* counts, int32_t cap, void* stream);
+
+/* Same for an integer activity tensor (decode_predictions' input): a run starts where a[t]-a[t-1] == 1 and
+ * ends where it == -1 (zero padded both ends), src/models/crnn/utils.py:83-87.  starts/ends are separate
+ * lists with separate counts (the reference zips them, which truncates to the shorter).
+ * act int32 [B][T][C]; starts/ends int32 [B][C][cap]; n_starts/n_ends int32 [B][C]. */
+int sed_activity_edges(const int32_t* act, int64_t B, int64_t T, int64_t C, int32_t* starts, int32_t* ends,
+                       int32_t* n_starts, int32_t* n_ends, int32_t cap, void* stream);
+
+/* Smoothing + per-frame argmax over classes + run-length over labels.
+ * Replaces get_events_from_batch (src/models/htsat/combined.py:26-71) and predict_class/predict_events
+ * (src/models/single_stage_yamnet_frame.py:174-208).  probs fp32 [B][T][C];
+ * runs int32 [B][cap][3] = (label, first frame, one past last frame), all labels including background;
+ * counts int32 [B].  drop_last_classes > 0 ignores that many trailing classes in the argmax. */
+int sed_argmax_runs(const float* probs, int64_t B, int64_t T, int64_t C, int32_t smoothing,
+                    int32_t drop_last_classes, int32_t* runs, int32_t* counts, int32_t cap, void* stream);
+
+/* Per-clip histogram of the per-frame argmax (trailing classes dropped): the majority vote of
+ * get_classification_events (src/models/htsat/classification.py:20-25).  hist int32 [B][C - drop_last]. */
+int sed_argmax_histogram(const float* probs, int64_t B, int64_t T, int64_t C, int32_t drop_last_classes,
+                         int32_t* hist, void* stream);
+
+/* Gap merge of onset-sorted event groups (one group = one (file, label) pair):
+ * next.onset - current.offset <= gap folds next into current, offset = max.
+ * Replaces the per-label loop of merge_close_events (src/utils/merge_events.py:36-55).
+ * onsets/offsets fp64 [n_events]; group_start int32 [n_groups+1] (prefix offsets);
+ * out_onsets/out_offsets fp64 [n_events] (merged events of group g at group_start[g] + i);
+ * out_counts int32 [n_groups]. */
+int sed_merge_events(const double* onsets, const double* offsets, const int32_t* group_start, int64_t n_groups,
+                     double gap, double* out_onsets, double* out_offsets, int32_t* out_counts, void* stream);
+
+/* Same merge on the frame-index runs written by sed_threshold_runs, with times looked up in a table
+ * (time_table[k] = the host-formatted time of frame k, fp64 [table_len]); n_groups = B*C.
+ * out_runs int32 [n_groups][cap][2]; out_counts int32 [n_groups]. */
+int sed_merge_runs(const int32_t* runs, const int32_t* counts, int64_t n_groups, int32_t cap,
+                   const double* time_table, int32_t table_len, double gap, int32_t* out_runs,
+                   int32_t* out_counts, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SED_HIP_H_ */

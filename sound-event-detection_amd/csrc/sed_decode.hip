@@ -1,0 +1,340 @@
+// Frame-level event decoders for gfx950: smoothing + threshold / argmax, run extraction and gap merging.
+// One 64-lane wavefront owns one trace (clip, class), one clip, or one (file, label) event group and walks
+// it in 64-element chunks; boundaries are found with ballots, output slots with popcounts of the ballot
+// below the lane, running maxima with shuffle scans.  No workgroup barriers, no atomics, results do not
+// depend on scheduling.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+// The fp64 smoothing and the gap compare must round exactly like the CPU code they mirror: no fused
+// multiply-add may be formed from a separate multiply and add anywhere in this file.
+#pragma clang fp contract(off)
+
+#include "sed_hip.h"
+
+namespace sed {
+
+// scipy.ndimage.gaussian_filter1d(sigma=3): radius 12, weights centre -> edge (fp64).
+__constant__ double kGauss3[13] = {
+    0x1.105a329f98197p-3, 0x1.01a25f86eb137p-3,  0x1.b42a57d56c0bep-4,  0x1.4a614d1afd337p-4, 0x1.bfde9c12bec92p-5,
+    0x1.0fa58939b528fp-5, 0x1.26defcaeb0202p-6,  0x1.1e6bccad344bap-7,  0x1.f1e9915139406p-9, 0x1.8345966f69518p-10,
+    0x1.0d8a5ad43c165p-11, 0x1.4fbe39149e277p-13, 0x1.763a210dfb306p-15};
+
+__device__ __forceinline__ uint64_t lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
+
+// Smoothed probability of frame t of a trace with element stride `stride`.  Frames are clamped to [0, T-1]
+// (scipy 'nearest' for the gaussian; 'reflect' of a 3-tap median duplicates the edge sample, same thing).
+// GAUSS25: fp64, acc = x0*w0, then j = 12..1: acc += (x[-j] + x[+j]) * w[j], separate multiply and add,
+// rounded once to fp32 -- scipy's correlate1d order, so the result has scipy's bits.
+__device__ __forceinline__ float smoothed(const float* x, int64_t stride, int t, int T, int smoothing) {
+  if (smoothing == SED_SMOOTH_NONE) return x[(int64_t)t * stride];
+  if (smoothing == SED_SMOOTH_MEDIAN3) {
+    const float a = x[(int64_t)max(t - 1, 0) * stride], b = x[(int64_t)t * stride];
+    const float c = x[(int64_t)min(t + 1, T - 1) * stride];
+    return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c));
+  }
+  double acc = __dmul_rn((double)x[(int64_t)t * stride], kGauss3[0]);
+#pragma unroll
+  for (int j = 12; j >= 1; --j) {
+    const double lo = (double)x[(int64_t)max(t - j, 0) * stride];
+    const double hi = (double)x[(int64_t)min(t + j, T - 1) * stride];
+    acc = __dadd_rn(acc, __dmul_rn(__dadd_rn(lo, hi), kGauss3[j]));
+  }
+  return (float)acc;
+}
+
+// ---- threshold runs -------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) threshold_runs_kernel(const float* probs, int64_t n_traces, int T, int C,
+                                                             float thr, int smoothing, int32_t* runs, int32_t* counts,
+                                                             int cap) {
+  const int lane = threadIdx.x & 63;
+  const int64_t trace = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (trace >= n_traces) return;
+  const int64_t b = trace / C;
+  const int c = (int)(trace - b * C);
+  const float* x = probs + b * (int64_t)T * C + c;
+  int32_t* out = runs + trace * (int64_t)cap * 2;
+  int n_runs = 0, n_ends = 0, carry = 0;
+  for (int t0 = 0; t0 <= T; t0 += 64) {  // frame T is a virtual inactive frame that closes a trailing run
+    const int t = t0 + lane;
+    const int act = (t < T) ? (smoothed(x, C, t, T, smoothing) > thr) : 0;
+    const uint64_t word = __ballot(act);
+    const int prev = lane ? (int)((word >> (lane - 1)) & 1ull) : carry;
+    const int is_start = act & !prev, is_end = (!act) & prev & (t <= T);
+    const uint64_t sm = __ballot(is_start), em = __ballot(is_end);
+    if (is_start) {
+      const int r = n_runs + __popcll(sm & lanemask_lt(lane));
+      if (r < cap) out[2 * r] = t;
+    }
+    if (is_end) {
+      const int r = n_ends + __popcll(em & lanemask_lt(lane));
+      if (r < cap) out[2 * r + 1] = t;
+    }
+    n_runs += __popcll(sm);
+    n_ends += __popcll(em);
+    carry = (int)(word >> 63);
+  }
+  if (lane == 0) counts[trace] = n_runs;
+}
+
+// ---- integer activity edges -----------------------------------------------------------------------
+__global__ void __launch_bounds__(256) activity_edges_kernel(const int32_t* act, int64_t n_traces, int T, int C,
+                                                             int32_t* starts, int32_t* ends, int32_t* n_starts,
+                                                             int32_t* n_ends, int cap) {
+  const int lane = threadIdx.x & 63;
+  const int64_t trace = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (trace >= n_traces) return;
+  const int64_t b = trace / C;
+  const int c = (int)(trace - b * C);
+  const int32_t* x = act + b * (int64_t)T * C + c;
+  int32_t* so = starts + trace * (int64_t)cap;
+  int32_t* eo = ends + trace * (int64_t)cap;
+  int ns = 0, ne = 0;
+  for (int t0 = 0; t0 <= T; t0 += 64) {
+    const int t = t0 + lane;
+    const int cur = (t < T) ? x[(int64_t)t * C] : 0;
+    const int prv = (t >= 1 && t <= T) ? x[(int64_t)(t - 1) * C] : 0;
+    const int64_t d = (int64_t)cur - (int64_t)prv;
+    const int is_s = (t <= T) && d == 1, is_e = (t <= T) && d == -1;
+    const uint64_t sm = __ballot(is_s), em = __ballot(is_e);
+    if (is_s) {
+      const int r = ns + __popcll(sm & lanemask_lt(lane));
+      if (r < cap) so[r] = t;
+    }
+    if (is_e) {
+      const int r = ne + __popcll(em & lanemask_lt(lane));
+      if (r < cap) eo[r] = t;
+    }
+    ns += __popcll(sm);
+    ne += __popcll(em);
+  }
+  if (lane == 0) { n_starts[trace] = ns; n_ends[trace] = ne; }
+}
+
+// ---- argmax runs ----------------------------------------------------------------------------------
+__device__ __forceinline__ int argmax_label(const float* row0, int t, int T, int C, int n_cls, int smoothing) {
+  // first maximum wins (numpy / torch CPU argmax)
+  int best = 0;
+  float bv = smoothed(row0, C, t, T, smoothing);
+  for (int c = 1; c < n_cls; ++c) {
+    const float v = smoothed(row0 + c, C, t, T, smoothing);
+    if (v > bv) { bv = v; best = c; }
+  }
+  return best;
+}
+
+__global__ void __launch_bounds__(256) argmax_runs_kernel(const float* probs, int64_t B, int T, int C, int smoothing,
+                                                          int drop_last, int32_t* runs, int32_t* counts, int cap) {
+  const int lane = threadIdx.x & 63;
+  const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const float* x = probs + b * (int64_t)T * C;
+  int32_t* out = runs + b * (int64_t)cap * 3;
+  const int n_cls = C - drop_last;
+  int n_runs = 0, carry_label = -1;
+  for (int t0 = 0; t0 < T; t0 += 64) {
+    const int t = t0 + lane;
+    const int lab = (t < T) ? argmax_label(x, t, T, C, n_cls, smoothing) : -2;
+    int prev = __shfl_up(lab, 1);
+    if (lane == 0) prev = carry_label;
+    const int boundary = (t < T) && (lab != prev);
+    const uint64_t bm = __ballot(boundary);
+    if (boundary) {
+      const int r = n_runs + __popcll(bm & lanemask_lt(lane));
+      if (r < cap) { out[3 * r] = lab; out[3 * r + 1] = t; }
+      if (r >= 1 && r - 1 < cap) out[3 * (r - 1) + 2] = t;
+    }
+    n_runs += __popcll(bm);
+    carry_label = __shfl(lab, 63);
+  }
+  if (lane == 0) {
+    if (n_runs >= 1 && n_runs - 1 < cap) out[3 * (n_runs - 1) + 2] = T;
+    counts[b] = n_runs;
+  }
+}
+
+__global__ void __launch_bounds__(256) argmax_hist_kernel(const float* probs, int64_t B, int T, int C, int drop_last,
+                                                          int32_t* hist) {
+  const int lane = threadIdx.x & 63;
+  const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const float* x = probs + b * (int64_t)T * C;
+  const int n_cls = C - drop_last;
+  int mine = 0;  // lane c accumulates the count of class c (n_cls <= 64)
+  for (int t0 = 0; t0 < T; t0 += 64) {
+    const int t = t0 + lane;
+    const int lab = (t < T) ? argmax_label(x, t, T, C, n_cls, SED_SMOOTH_NONE) : -1;
+    for (int c = 0; c < n_cls; ++c) {
+      const int n = __popcll(__ballot(lab == c));
+      if (lane == c) mine += n;
+    }
+  }
+  if (lane < n_cls) hist[b * n_cls + lane] = mine;
+}
+
+// ---- gap merge ------------------------------------------------------------------------------------
+// Sequential rule per group (events sorted by onset): fold next into current when
+// next.onset - current.offset <= gap, current.offset = max(current.offset, next.offset).
+// Parallel form: with P_i = max of ALL earlier offsets in the group, "fl(onset_i - P_i) > gap" marks exactly
+// the events that open a new merged event (onsets ascend and fl(a - b) is monotone in b, so an offset from
+// an already closed merged event can only be the maximum when the current one would break anyway);
+// a merged event's offset is the maximum offset between two consecutive marks.
+template <bool FROM_RUNS>
+__global__ void __launch_bounds__(256) merge_kernel(const double* onsets, const double* offsets,
+                                                    const int32_t* group_start, const int32_t* runs,
+                                                    const int32_t* counts, int cap, const double* table, int table_len,
+                                                    int64_t n_groups, double gap, double* out_on, double* out_off,
+                                                    int32_t* out_runs, int32_t* out_counts) {
+  const int lane = threadIdx.x & 63;
+  const int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (g >= n_groups) return;
+  int64_t base;
+  int n;
+  if (FROM_RUNS) { base = g * (int64_t)cap; n = min(counts[g], cap); }
+  else { base = group_start[g]; n = group_start[g + 1] - group_start[g]; }
+  int n_out = 0;
+  double carry_pmax = -INFINITY;   // max of all offsets seen so far in the group
+  double carry_smax = -INFINITY;   // max offset of the merged event that is still open
+  int carry_sidx = 0;              // frame index behind carry_smax (FROM_RUNS)
+  for (int i0 = 0; i0 < n; i0 += 64) {
+    const int i = i0 + lane;
+    const bool valid = i < n;
+    double on = INFINITY, off = -INFINITY;
+    int on_k = 0, off_k = 0;
+    if (valid) {
+      if (FROM_RUNS) {
+        on_k = runs[(base + i) * 2];
+        off_k = runs[(base + i) * 2 + 1];
+        on = table[min(max(on_k, 0), table_len - 1)];
+        off = table[min(max(off_k, 0), table_len - 1)];
+      } else {
+        on = onsets[base + i];
+        off = offsets[base + i];
+      }
+    }
+    // exclusive prefix max of offsets over the whole group
+    double inc = off;
+    for (int d = 1; d < 64; d <<= 1) {
+      const double o = __shfl_up(inc, d);
+      if (lane >= d) inc = fmax(inc, o);
+    }
+    double exc = __shfl_up(inc, 1);
+    if (lane == 0) exc = -INFINITY;
+    exc = fmax(exc, carry_pmax);
+    const bool head = valid && ((i == 0) || (__dsub_rn(on, exc) > gap));
+    const uint64_t hm = __ballot(head);
+    // forward max over the lanes of the same merged event inside this chunk
+    const uint64_t below = hm & (lanemask_lt(lane) | (1ull << lane));
+    const int seg_lo = below ? 63 - __clzll(below) : 0;
+    double smax = off;
+    int sidx = off_k;
+    for (int d = 1; d < 64; d <<= 1) {
+      const double o = __shfl_up(smax, d);
+      const int oi = __shfl_up(sidx, d);
+      if (lane - d >= seg_lo && o > smax) { smax = o; sidx = oi; }
+    }
+    if (!below && carry_smax > smax) { smax = carry_smax; sidx = carry_sidx; }  // continues the open event
+    // a head closes the previous merged event with the running max of the lane before it
+    double prev_smax = __shfl_up(smax, 1);
+    int prev_sidx = __shfl_up(sidx, 1);
+    if (lane == 0) { prev_smax = carry_smax; prev_sidx = carry_sidx; }
+    if (head) {
+      const int r = n_out + __popcll(hm & lanemask_lt(lane));
+      if (FROM_RUNS) {
+        out_runs[(base + r) * 2] = on_k;
+        if (r >= 1) out_runs[(base + r - 1) * 2 + 1] = prev_sidx;
+      } else {
+        out_on[base + r] = on;
+        if (r >= 1) out_off[base + r - 1] = prev_smax;
+      }
+    }
+    n_out += __popcll(hm);
+    const int last = min(63, n - 1 - i0);
+    carry_pmax = fmax(carry_pmax, __shfl(inc, last));
+    carry_smax = __shfl(smax, last);
+    carry_sidx = __shfl(sidx, last);
+  }
+  if (lane == 0) {
+    if (n_out >= 1) {
+      if (FROM_RUNS) out_runs[(base + n_out - 1) * 2 + 1] = carry_sidx;
+      else out_off[base + n_out - 1] = carry_smax;
+    }
+    out_counts[g] = n_out;
+  }
+}
+
+}  // namespace sed
+
+using namespace sed;
+
+static inline int hip_status(hipError_t e) { return e == hipSuccess ? SED_OK : SED_ERR_HIP - (int)e; }
+static inline unsigned blocks_for(int64_t waves) { return (unsigned)((waves + 3) / 4); }
+
+extern "C" int sed_threshold_runs(const float* probs, int64_t B, int64_t T, int64_t C, float threshold,
+                                  int32_t smoothing, int32_t* runs, int32_t* counts, int32_t cap, void* stream) {
+  if (B < 0 || T < 0 || C < 0 || cap < 1 || smoothing < 0 || smoothing > 2) return SED_ERR_BAD_ARG;
+  if (T >= INT32_MAX - 64 || C > INT32_MAX || B * C > (int64_t)INT32_MAX * 4) return SED_ERR_BAD_ARG;
+  if (B * C == 0) return SED_OK;
+  if (!counts || !runs || (T > 0 && !probs)) return SED_ERR_BAD_ARG;
+  hipLaunchKernelGGL(threshold_runs_kernel, dim3(blocks_for(B * C)), dim3(256), 0, (hipStream_t)stream, probs, B * C,
+                     (int)T, (int)C, threshold, (int)smoothing, runs, counts, (int)cap);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int sed_activity_edges(const int32_t* act, int64_t B, int64_t T, int64_t C, int32_t* starts, int32_t* ends,
+                                  int32_t* n_starts, int32_t* n_ends, int32_t cap, void* stream) {
+  if (B < 0 || T < 0 || C < 0 || cap < 1) return SED_ERR_BAD_ARG;
+  if (T >= INT32_MAX - 64 || C > INT32_MAX || B * C > (int64_t)INT32_MAX * 4) return SED_ERR_BAD_ARG;
+  if (B * C == 0) return SED_OK;
+  if (!starts || !ends || !n_starts || !n_ends || (T > 0 && !act)) return SED_ERR_BAD_ARG;
+  hipLaunchKernelGGL(activity_edges_kernel, dim3(blocks_for(B * C)), dim3(256), 0, (hipStream_t)stream, act, B * C,
+                     (int)T, (int)C, starts, ends, n_starts, n_ends, (int)cap);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int sed_argmax_runs(const float* probs, int64_t B, int64_t T, int64_t C, int32_t smoothing,
+                               int32_t drop_last_classes, int32_t* runs, int32_t* counts, int32_t cap, void* stream) {
+  if (B < 0 || T < 0 || C < 1 || cap < 1 || smoothing < 0 || smoothing > 2) return SED_ERR_BAD_ARG;
+  if (drop_last_classes < 0 || drop_last_classes >= C || T >= INT32_MAX - 64 || C > INT32_MAX) return SED_ERR_BAD_ARG;
+  if (B == 0) return SED_OK;
+  if (!runs || !counts || (T > 0 && !probs)) return SED_ERR_BAD_ARG;
+  hipLaunchKernelGGL(argmax_runs_kernel, dim3(blocks_for(B)), dim3(256), 0, (hipStream_t)stream, probs, B, (int)T,
+                     (int)C, (int)smoothing, (int)drop_last_classes, runs, counts, (int)cap);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int sed_argmax_histogram(const float* probs, int64_t B, int64_t T, int64_t C, int32_t drop_last_classes,
+                                    int32_t* hist, void* stream) {
+  if (B < 0 || T < 0 || C < 1 || drop_last_classes < 0 || drop_last_classes >= C) return SED_ERR_BAD_ARG;
+  if (C - drop_last_classes > 64 || T >= INT32_MAX - 64) return SED_ERR_BAD_ARG;
+  if (B == 0) return SED_OK;
+  if (!hist || (T > 0 && !probs)) return SED_ERR_BAD_ARG;
+  hipLaunchKernelGGL(argmax_hist_kernel, dim3(blocks_for(B)), dim3(256), 0, (hipStream_t)stream, probs, B, (int)T,
+                     (int)C, (int)drop_last_classes, hist);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int sed_merge_events(const double* onsets, const double* offsets, const int32_t* group_start,
+                                int64_t n_groups, double gap, double* out_onsets, double* out_offsets,
+                                int32_t* out_counts, void* stream) {
+  if (n_groups < 0) return SED_ERR_BAD_ARG;
+  if (n_groups == 0) return SED_OK;
+  if (!onsets || !offsets || !group_start || !out_onsets || !out_offsets || !out_counts) return SED_ERR_BAD_ARG;
+  hipLaunchKernelGGL(merge_kernel<false>, dim3(blocks_for(n_groups)), dim3(256), 0, (hipStream_t)stream, onsets,
+                     offsets, group_start, nullptr, nullptr, 0, nullptr, 0, n_groups, gap, out_onsets, out_offsets,
+                     nullptr, out_counts);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int sed_merge_runs(const int32_t* runs, const int32_t* counts, int64_t n_groups, int32_t cap,
+                              const double* time_table, int32_t table_len, double gap, int32_t* out_runs,
+                              int32_t* out_counts, void* stream) {
+  if (n_groups < 0 || cap < 1 || table_len < 1) return SED_ERR_BAD_ARG;
+  if (n_groups == 0) return SED_OK;
+  if (!runs || !counts || !time_table || !out_runs || !out_counts) return SED_ERR_BAD_ARG;
+  hipLaunchKernelGGL(merge_kernel<true>, dim3(blocks_for(n_groups)), dim3(256), 0, (hipStream_t)stream, nullptr,
+                     nullptr, nullptr, runs, counts, (int)cap, time_table, (int)table_len, n_groups, gap, nullptr,
+                     nullptr, out_runs, out_counts);
+  return hip_status(hipGetLastError());
+}

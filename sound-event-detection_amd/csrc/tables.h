@@ -1,0 +1,159 @@
+// Host-side table builders (fp64 arithmetic, rounded once to fp32): window, FFT twiddles for the lane
+// decomposition in fft_core.h, mel filterbanks, and the banded/lane-scheduled form of a mel matrix.
+#pragma once
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <numeric>
+#include <vector>
+
+#include "fft_core.h"
+
+namespace sed {
+
+constexpr double kPi = 3.14159265358979323846264338327950288;
+
+// Periodic Hann of win_length placed in n_fft samples: centred (librosa pad_center) or left aligned
+// (tf.signal.stft zero-extends the frame at its end).
+inline std::vector<double> build_window(int n_fft, int win_length, bool left_aligned) {
+  std::vector<double> w(n_fft, 0.0);
+  const int off = left_aligned ? 0 : (n_fft - win_length) / 2;
+  for (int n = 0; n < win_length; ++n) w[off + n] = 0.5 - 0.5 * std::cos(2.0 * kPi * n / win_length);
+  return w;
+}
+
+inline cplx unit_root(int64_t num, int64_t den) {  // exp(-2 pi i num/den), argument reduced exactly
+  num %= den;
+  const double a = -2.0 * kPi * (double)num / (double)den;
+  return cplx{(float)std::cos(a), (float)std::sin(a)};
+}
+
+template <class G>
+std::vector<cplx> build_tw1() {  // [k1*R2 + n2] = W_NC^(n2 k1)
+  std::vector<cplx> t(G::R1 * G::R2);
+  for (int k1 = 0; k1 < G::R1; ++k1)
+    for (int n2 = 0; n2 < G::R2; ++n2) t[k1 * G::R2 + n2] = unit_root((int64_t)n2 * k1, G::NC);
+  return t;
+}
+
+template <class G>
+std::vector<cplx> build_tw2() {  // [s*LPF + l] = W_NFFT^(bin of slot s in lane l)
+  std::vector<cplx> t(G::SLOTS * G::LPF);
+  for (int s = 0; s < G::SLOTS; ++s)
+    for (int l = 0; l < G::LPF; ++l) t[s * G::LPF + l] = unit_root(lane_slot_bin<G>(l, s), G::NFFT);
+  return t;
+}
+
+// ---- mel filterbanks -------------------------------------------------------------------------------
+
+// numpy.linspace(start, stop, num): arange(num) * ((stop-start)/(num-1)) + start, last point = stop.
+inline std::vector<double> linspace(double start, double stop, int num) {
+  std::vector<double> y(num);
+  const double step = (stop - start) / (num - 1);
+  for (int i = 0; i < num; ++i) y[i] = i * step + start;
+  y[num - 1] = stop;
+  return y;
+}
+
+inline double hz_to_mel_slaney(double f) {
+  const double f_sp = 200.0 / 3, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp;
+  const double logstep = std::log(6.4) / 27.0;
+  return f >= min_log_hz ? min_log_mel + std::log(f / min_log_hz) / logstep : f / f_sp;
+}
+inline double mel_to_hz_slaney(double m) {
+  const double f_sp = 200.0 / 3, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp;
+  const double logstep = std::log(6.4) / 27.0;
+  return m >= min_log_mel ? min_log_hz * std::exp(logstep * (m - min_log_mel)) : f_sp * m;
+}
+
+// librosa.filters.mel(htk=False, norm='slaney') transposed: melW[k*n_mels + m], k = 0..n_fft/2.
+inline std::vector<float> mel_slaney(int sr, int n_fft, int n_mels, double fmin, double fmax) {
+  const int F = n_fft / 2 + 1;
+  std::vector<double> pts = linspace(hz_to_mel_slaney(fmin), hz_to_mel_slaney(fmax), n_mels + 2);
+  for (double& p : pts) p = mel_to_hz_slaney(p);
+  const std::vector<double> freqs = linspace(0.0, (double)sr / 2, F);
+  std::vector<float> w((size_t)F * n_mels, 0.0f);
+  for (int m = 0; m < n_mels; ++m) {
+    const double enorm = 2.0 / (pts[m + 2] - pts[m]);
+    for (int k = 0; k < F; ++k) {
+      const double f = freqs[k];
+      const double lower = (f - pts[m]) / (pts[m + 1] - pts[m]);
+      const double upper = (pts[m + 2] - f) / (pts[m + 2] - pts[m + 1]);
+      w[(size_t)k * n_mels + m] = (float)(std::max(0.0, std::min(lower, upper)) * enorm);
+    }
+  }
+  return w;
+}
+
+// tf.signal.linear_to_mel_weight_matrix: HTK mel, triangles linear in mel, peak 1, DC row zero.
+inline std::vector<float> mel_htk_tf(int sr, int n_fft, int n_mels, double fmin, double fmax) {
+  const int F = n_fft / 2 + 1;
+  auto h2m = [](double f) { return 1127.0 * std::log1p(f / 700.0); };
+  const std::vector<double> e = linspace(h2m(fmin), h2m(fmax), n_mels + 2);
+  const std::vector<double> freqs = linspace(0.0, (double)sr / 2, F);
+  std::vector<float> w((size_t)F * n_mels, 0.0f);
+  for (int k = 1; k < F; ++k) {
+    const double mel = h2m(freqs[k]);
+    for (int m = 0; m < n_mels; ++m) {
+      const double lower = (mel - e[m]) / (e[m + 1] - e[m]);
+      const double upper = (e[m + 2] - mel) / (e[m + 2] - e[m + 1]);
+      w[(size_t)k * n_mels + m] = (float)std::max(0.0, std::min(lower, upper));
+    }
+  }
+  return w;
+}
+
+// ---- banded form + per-lane schedule ---------------------------------------------------------------
+
+struct alignas(16) MelEntry {  // one mel filter as seen by the lane that evaluates it
+  int32_t mel;     // output index, -1 = padding entry
+  int32_t start;   // first bin of the band
+  int32_t len;     // number of consecutive bins (0 = empty filter)
+  int32_t woff;    // offset of its weights in the packed weight array
+};
+
+struct MelSchedule {
+  int lanes = 0, slots = 0;            // entries[lane*slots + j]
+  std::vector<MelEntry> entries;
+  std::vector<float> weights;          // bands back to back
+};
+
+// Compress a dense [F][M] matrix to one contiguous band per filter and spread the filters over `lanes`
+// lanes so that the per-lane sums of band lengths are balanced (longest first, to the least loaded lane).
+inline MelSchedule schedule_mel(const std::vector<float>& melW, int F, int M, int lanes) {
+  MelSchedule s;
+  s.lanes = lanes;
+  s.slots = (M + lanes - 1) / lanes;
+  std::vector<MelEntry> bands(M);
+  for (int m = 0; m < M; ++m) {
+    int lo = F, hi = -1;
+    for (int k = 0; k < F; ++k)
+      if (melW[(size_t)k * M + m] != 0.0f) { lo = std::min(lo, k); hi = std::max(hi, k); }
+    MelEntry e{m, 0, 0, (int32_t)s.weights.size()};
+    if (hi >= lo) {
+      e.start = lo; e.len = hi - lo + 1;
+      for (int k = lo; k <= hi; ++k) s.weights.push_back(melW[(size_t)k * M + m]);
+    }
+    bands[m] = e;
+  }
+  std::vector<int> order(M);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return bands[a].len > bands[b].len; });
+  std::vector<std::vector<MelEntry>> per(lanes);
+  std::vector<int> load(lanes, 0);
+  for (int m : order) {
+    int best = -1;
+    for (int l = 0; l < lanes; ++l)
+      if ((int)per[l].size() < s.slots && (best < 0 || load[l] < load[best])) best = l;
+    per[best].push_back(bands[m]);
+    load[best] += bands[m].len;
+  }
+  s.entries.assign((size_t)lanes * s.slots, MelEntry{-1, 0, 0, 0});
+  for (int l = 0; l < lanes; ++l)
+    for (size_t j = 0; j < per[l].size(); ++j) s.entries[(size_t)l * s.slots + j] = per[l][j];
+  if (s.weights.empty()) s.weights.push_back(0.0f);
+  return s;
+}
+
+}  // namespace sed

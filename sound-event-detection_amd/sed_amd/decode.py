@@ -1,0 +1,337 @@
+"""Frame-level event decoders running on the HIP kernels of libsedhip.so.
+
+Same names, argument meaning and output format as the reference functions they replace:
+
+  detect_onsets_offsets      src/models/yamnet_train.py:55-71
+  decode_predictions         src/models/crnn/utils.py:91-134   (binary activity -> events)
+  decode_probabilities       src/models/crnn/crnn.py:418-425 + :454-459 fused (smooth, threshold, decode)
+  merge_close_events         src/utils/merge_events.py:4-60
+  process_json_file          src/utils/merge_events.py:63-87
+  get_events_from_batch      src/models/htsat/combined.py:17-73
+  predict_events             src/models/single_stage_yamnet_frame.py:185-209
+  get_classification_label   src/models/htsat/classification.py:20-26
+
+The kernels return integer frame indices (and, for the gap merge, select among the caller's fp64 times);
+every time value is formed on the host with the reference's own Python expression, so event lists are
+bit-identical given identical frame probabilities.  There is no CPU path.
+"""
+from __future__ import annotations
+
+import json
+import os
+from typing import Any, Dict, List, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+CLASSES = ["cough", "dog_bark", "gun_shot", "siren", "car_horn"]           # src/config.py:4
+NON_EVENT_LABEL = "non_event"                                               # src/models/htsat/constants.py:8
+_SMOOTH = {None: L.SMOOTH_NONE, "none": L.SMOOTH_NONE, "median3": L.SMOOTH_MEDIAN3, "gauss": L.SMOOTH_GAUSS25}
+
+
+def _device() -> torch.device:
+    if not torch.cuda.is_available():
+        raise RuntimeError("no ROCm device is visible; the decoders have no CPU path")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _to_dev(x, dtype) -> torch.Tensor:
+    t = torch.as_tensor(x)
+    if not t.is_cuda:
+        t = t.to(_device())
+    return t.to(dtype).contiguous()
+
+
+# ---- kernel wrappers (device tensors in, device tensors out, no host sync) ---------------------------------
+
+
+def threshold_runs(probs: torch.Tensor, threshold: float, smoothing=None):
+    """probs (B, T, C) fp32 on device -> (runs int32 (B, C, cap, 2), counts int32 (B, C)); cap = T//2 + 1."""
+    B, T, Cn = probs.shape
+    cap = T // 2 + 1
+    runs = torch.empty((B, Cn, cap, 2), dtype=torch.int32, device=probs.device)
+    counts = torch.zeros((B, Cn), dtype=torch.int32, device=probs.device)
+    with torch.cuda.device(probs.device):
+        L.check(L.lib.sed_threshold_runs(probs.data_ptr(), B, T, Cn, float(np.float32(threshold)), _SMOOTH[smoothing],
+                                         runs.data_ptr(), counts.data_ptr(), cap, L.stream_ptr(probs.device)),
+                "sed_threshold_runs")
+    return runs, counts
+
+
+def activity_edges(act: torch.Tensor):
+    """act (B, T, C) int32 on device -> starts, ends (B, C, cap), n_starts, n_ends (B, C); cap = T + 1."""
+    B, T, Cn = act.shape
+    cap = T + 1
+    starts = torch.empty((B, Cn, cap), dtype=torch.int32, device=act.device)
+    ends = torch.empty_like(starts)
+    ns = torch.zeros((B, Cn), dtype=torch.int32, device=act.device)
+    ne = torch.zeros_like(ns)
+    with torch.cuda.device(act.device):
+        L.check(L.lib.sed_activity_edges(act.data_ptr(), B, T, Cn, starts.data_ptr(), ends.data_ptr(), ns.data_ptr(),
+                                         ne.data_ptr(), cap, L.stream_ptr(act.device)), "sed_activity_edges")
+    return starts, ends, ns, ne
+
+
+def argmax_runs(probs: torch.Tensor, smoothing=None, drop_last_classes: int = 0):
+    """probs (B, T, C) fp32 on device -> (runs int32 (B, T, 3) = (label, start, end), counts int32 (B,))."""
+    B, T, Cn = probs.shape
+    cap = max(T, 1)
+    runs = torch.empty((B, cap, 3), dtype=torch.int32, device=probs.device)
+    counts = torch.zeros((B,), dtype=torch.int32, device=probs.device)
+    with torch.cuda.device(probs.device):
+        L.check(L.lib.sed_argmax_runs(probs.data_ptr(), B, T, Cn, _SMOOTH[smoothing], drop_last_classes,
+                                      runs.data_ptr(), counts.data_ptr(), cap, L.stream_ptr(probs.device)),
+                "sed_argmax_runs")
+    return runs, counts
+
+
+def argmax_histogram(probs: torch.Tensor, drop_last_classes: int = 0) -> torch.Tensor:
+    B, T, Cn = probs.shape
+    hist = torch.zeros((B, Cn - drop_last_classes), dtype=torch.int32, device=probs.device)
+    with torch.cuda.device(probs.device):
+        L.check(L.lib.sed_argmax_histogram(probs.data_ptr(), B, T, Cn, drop_last_classes, hist.data_ptr(),
+                                           L.stream_ptr(probs.device)), "sed_argmax_histogram")
+    return hist
+
+
+def merge_runs(runs: torch.Tensor, counts: torch.Tensor, time_table: torch.Tensor, gap: float):
+    """Gap-merge frame-index runs (.., cap, 2) group by group using fp64 times time_table[frame]."""
+    cap = runs.shape[-2]
+    n_groups = counts.numel()
+    out_runs = torch.empty_like(runs)
+    out_counts = torch.zeros_like(counts)
+    with torch.cuda.device(runs.device):
+        L.check(L.lib.sed_merge_runs(runs.data_ptr(), counts.data_ptr(), n_groups, cap, time_table.data_ptr(),
+                                     time_table.numel(), float(gap), out_runs.data_ptr(), out_counts.data_ptr(),
+                                     L.stream_ptr(runs.device)), "sed_merge_runs")
+    return out_runs, out_counts
+
+
+def merge_event_groups(onsets: torch.Tensor, offsets: torch.Tensor, group_start: torch.Tensor, gap: float):
+    """fp64 onsets/offsets (n,), group_start int32 (G+1,) -> merged onsets, offsets (n,), counts (G,)."""
+    G = group_start.numel() - 1
+    out_on = torch.empty_like(onsets)
+    out_off = torch.empty_like(offsets)
+    out_counts = torch.zeros((max(G, 0),), dtype=torch.int32, device=onsets.device)
+    with torch.cuda.device(onsets.device):
+        L.check(L.lib.sed_merge_events(onsets.data_ptr(), offsets.data_ptr(), group_start.data_ptr(), G, float(gap),
+                                       out_on.data_ptr(), out_off.data_ptr(), out_counts.data_ptr(),
+                                       L.stream_ptr(onsets.device)), "sed_merge_events")
+    return out_on, out_off, out_counts
+
+
+# ---- D1 --------------------------------------------------------------------------------------------------
+
+
+def detect_onsets_offsets(preds, threshold=0.5, hop_time=0.48, med_filter=True):
+    """Framewise probabilities (N,) -> (onsets, offsets) in seconds (fp64 arrays)."""
+    on, off = detect_onsets_offsets_batch(torch.as_tensor(preds)[None], threshold, hop_time, med_filter)[0]
+    return on, off
+
+
+def detect_onsets_offsets_batch(preds, threshold=0.5, hop_time=0.48, med_filter=True):
+    """(B, N) probabilities -> list of (onsets, offsets) per stream, each exactly what the reference returns."""
+    p = _to_dev(preds, torch.float32)
+    B, N = p.shape
+    runs, counts = threshold_runs(p[:, :, None], threshold, "median3" if med_filter else None)
+    runs, counts = runs[:, 0].cpu().numpy(), counts[:, 0].cpu().numpy()
+    out = []
+    for b in range(B):
+        r = runs[b, :counts[b]]
+        # the reference diffs the UNPADDED trace: a run starting at frame 0 has no onset, one ending at N no offset
+        on_k = r[r[:, 0] >= 1, 0].astype(np.int64)
+        off_k = r[r[:, 1] <= N - 1, 1].astype(np.int64)
+        onsets = on_k * hop_time
+        offsets = off_k * hop_time
+        if len(offsets) < len(onsets):
+            offsets = np.append(offsets, (N + 1) * hop_time)
+        elif len(offsets) > len(onsets):
+            onsets = np.append(0, onsets)
+        out.append((onsets, offsets))
+    return out
+
+
+# ---- D2 + D3 ---------------------------------------------------------------------------------------------
+
+
+def _format_events(results, filenames, class_labels, frames_per_sec, n_files, get_pairs):
+    time_resolution = 1.0 / frames_per_sec
+    for i in range(n_files):
+        if i >= len(filenames):
+            break
+        filename = filenames[i]
+        if isinstance(filename, np.ndarray):
+            filename = filename.item()
+        filename = str(filename)
+        results[filename] = []
+        for class_idx, label in class_labels.items():
+            for s, e in get_pairs(i, class_idx):
+                results[filename].append({"file": filename, "event_onset": round(int(s) * time_resolution, 3),
+                                          "event_offset": round(int(e) * time_resolution, 3), "event_label": label})
+    return results
+
+
+def decode_predictions(preds, filenames, class_labels, frames_per_sec):
+    """Binary activity (N, T, C) -> {file: [{'file','event_onset','event_offset','event_label'}]}."""
+    a = _to_dev(preds, torch.int32)
+    starts, ends, ns, ne = (t.cpu().numpy() for t in activity_edges(a))
+
+    def pairs(i, c):
+        n = min(ns[i, c], ne[i, c])
+        return zip(starts[i, c, :n], ends[i, c, :n])
+
+    return _format_events({}, filenames, class_labels, frames_per_sec, a.shape[0], pairs)
+
+
+def decode_probabilities(probs, filenames, class_labels, frames_per_sec, posterior_thresh=0.5, smoothing="gauss"):
+    """Sigmoid outputs (N, T, C) -> events: gaussian smoothing (sigma 3, 'nearest'), strict threshold, run decode."""
+    p = _to_dev(probs, torch.float32)
+    runs, counts = threshold_runs(p, posterior_thresh, smoothing)
+    runs, counts = runs.cpu().numpy(), counts.cpu().numpy()
+
+    def pairs(i, c):
+        return runs[i, c, :counts[i, c]]
+
+    return _format_events({}, filenames, class_labels, frames_per_sec, p.shape[0], pairs)
+
+
+# ---- D4 --------------------------------------------------------------------------------------------------
+
+
+def merge_close_events_batch(events_by_file: Dict[str, List[Dict[str, Any]]], threshold: float = 0.5):
+    """merge_close_events for every file of a results dict with ONE kernel launch."""
+    keys = list(events_by_file.keys())
+    heads: List[List[Dict[str, Any]]] = []   # per group: its events in onset order
+    owner: List[int] = []                    # per group: index of the file
+    for fi, k in enumerate(keys):
+        events = events_by_file[k]
+        if not events:
+            continue
+        sorted_events = sorted(events, key=lambda x: x["event_onset"])
+        by_label: Dict[Any, List[Dict[str, Any]]] = {}
+        for ev in sorted_events:
+            by_label.setdefault(ev["event_label"], []).append(ev)
+        for label_events in by_label.values():
+            heads.append(label_events)
+            owner.append(fi)
+    out = {k: [] for k in keys}
+    if heads:
+        sizes = np.asarray([len(g) for g in heads], dtype=np.int64)
+        group_start = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+        on = np.asarray([ev["event_onset"] for g in heads for ev in g], dtype=np.float64)
+        off = np.asarray([ev["event_offset"] for g in heads for ev in g], dtype=np.float64)
+        dev = _device()
+        m_on, m_off, m_cnt = merge_event_groups(torch.from_numpy(on).to(dev), torch.from_numpy(off).to(dev),
+                                                torch.from_numpy(group_start).to(dev), threshold)
+        m_on, m_off, m_cnt = m_on.cpu().numpy(), m_off.cpu().numpy(), m_cnt.cpu().numpy()
+        for gi, g in enumerate(heads):
+            base = int(group_start[gi])
+            # a merged event is a copy of the first event folded into it; find that event by walking the group
+            j = 0
+            for r in range(int(m_cnt[gi])):
+                while g[j]["event_onset"] != m_on[base + r]:
+                    j += 1
+                ev = g[j].copy()
+                ev["event_offset"] = float(m_off[base + r])
+                out[keys[owner[gi]]].append(ev)
+                j += 1
+    for k in keys:
+        out[k].sort(key=lambda x: x["event_onset"])
+    return out
+
+
+def merge_close_events(events: List[Dict[str, Any]], threshold: float = 0.5) -> List[Dict[str, Any]]:
+    """Merge events of one file that share a label when the gap to the previous offset is <= threshold."""
+    if not events:
+        return []
+    return merge_close_events_batch({"_": events}, threshold)["_"]
+
+
+def process_json_file(input_file: str, output_file: str, threshold: float = 0.5):
+    with open(input_file, "r") as f:
+        data = json.load(f)
+    merged_data = merge_close_events_batch(data, threshold)
+    for filename, events in data.items():
+        print(f"Processed {filename}: {len(events)} -> {len(merged_data[filename])} events")
+    with open(output_file, "w") as f:
+        json.dump(merged_data, f, indent=4)
+    print(f"\nMerged results saved to {output_file}")
+
+
+# ---- D5 --------------------------------------------------------------------------------------------------
+
+
+def get_events_from_batch(batch, config, class_names: Sequence[str] = tuple(CLASSES + [NON_EVENT_LABEL]),
+                          non_event_label: str = NON_EVENT_LABEL):
+    """batch = {'file': [...], 'pred_map': (B, T, C)}; config.clip_duration in seconds.
+
+    As in the reference only element 0 of the batch is decoded, interior boundaries are reported one frame
+    late (its loop index is 1-based) and the last offset is exactly clip_duration.
+    """
+    non_event = list(class_names).index(non_event_label)
+    file = batch["file"]
+    pred_map = _to_dev(batch["pred_map"], torch.float32)
+    batch_size, num_frame, num_classes = pred_map.shape
+    runs, counts = argmax_runs(pred_map[:1], "gauss")
+    runs, n = runs[0].cpu().numpy(), int(counts[0].item())
+    file_record = file[0]
+    file_events = []
+    for label, s, e in runs[:n]:
+        if label == non_event:
+            continue
+        onset_frame = 0 if s == 0 else int(s) + 1
+        i = num_frame if e == num_frame else int(e) + 1
+        file_events.append({"file": file_record, "event_onset": onset_frame / num_frame * config.clip_duration,
+                            "event_offset": i / num_frame * config.clip_duration,
+                            "event_label": class_names[int(label)]})
+    return {file_record: file_events}
+
+
+def get_events(frame_predictions, config, **kw):
+    """src/models/htsat/combined.py:75-80."""
+    pred_event_dict = {}
+    for batch in frame_predictions:
+        pred_event_dict = pred_event_dict | get_events_from_batch(batch, config, **kw)
+    return pred_event_dict
+
+
+# ---- D6 --------------------------------------------------------------------------------------------------
+
+
+def predict_events(frame_probs, file, classes: Sequence[str] = tuple(CLASSES), frame_hop_sec=0.48, med_filter=False):
+    """frame_probs (n_frames, 1 + len(classes)) with class 0 = background -> events of one file."""
+    return predict_events_batch(torch.as_tensor(frame_probs)[None], [file], classes, frame_hop_sec, med_filter)[0]
+
+
+def predict_events_batch(frame_probs, files, classes: Sequence[str] = tuple(CLASSES), frame_hop_sec=0.48,
+                         med_filter=False):
+    p = _to_dev(frame_probs, torch.float32)
+    runs, counts = argmax_runs(p, "median3" if med_filter else None)
+    runs, counts = runs.cpu().numpy(), counts.cpu().numpy()
+    out = []
+    for b, file in enumerate(files):
+        filename = os.path.basename(file)
+        events = []
+        for label, s, e in runs[b, :counts[b]]:
+            if label == 0:
+                continue
+            events.append({"file": filename, "event_onset": int(s) * frame_hop_sec, "event_offset": int(e) * frame_hop_sec,
+                           "event_label": classes[int(label) - 1]})
+        out.append(events)
+    return out
+
+
+# ---- D7 --------------------------------------------------------------------------------------------------
+
+
+def get_classification_label(pred_map, class_names: Sequence[str] = tuple(CLASSES + [NON_EVENT_LABEL])):
+    """pred_map (T, C) or (B, T, C): drop the last class, per-frame argmax, majority vote (smallest id wins ties)."""
+    p = _to_dev(pred_map, torch.float32)
+    single = p.dim() == 2
+    if single:
+        p = p[None]
+    hist = argmax_histogram(p, drop_last_classes=1).cpu().numpy()
+    labels = [class_names[int(np.argmax(h))] for h in hist]
+    return labels[0] if single else labels

@@ -1,0 +1,458 @@
+"""Drop-in log-mel front-ends running on the HIP kernels of libsedhip.so.
+
+Mirrors, for inference, the interfaces the reference calls:
+
+  Spectrogram / LogmelFilterBank   torchlibrosa modules as constructed at
+                                   external/hts_audio_transformer/model/htsat.py:453-459 and called at :763-764
+  LogMelFrontend                   the two fused into one launch (the (T, F) spectrogram is never written)
+  yamnet_log_mel                   output #3 of yamnet_model(audio), src/models/yamnet_train.py:47
+  extract_mbe                      src/models/crnn/process_audio.py:29-34
+  get_mel_spec_db                  src/utils/audio_to_spectrograms.py:30-44 (on samples instead of a file path)
+
+All outputs are fresh contiguous fp32 tensors on the input's device; inputs are never modified.  The kernels
+are inference-only: outputs do not carry autograd history.  There is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import dataclasses
+import math
+from typing import Optional
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib as L
+
+
+@dataclasses.dataclass(frozen=True)
+class FrontendConfig:
+    """One front-end flavour (field-for-field sed_frontend_cfg)."""
+    sample_rate: int
+    n_fft: int
+    win_length: int
+    hop: int
+    center: bool = True
+    pad_mode: int = L.PAD_REFLECT
+    win_align: int = L.WIN_CENTER
+    tail_min_samples: int = 0
+    tail_hop_samples: int = 0
+    spectrum: int = L.SPEC_POWER
+    mel_kind: int = L.MEL_SLANEY
+    n_mels: int = 64
+    fmin: float = 0.0
+    fmax: float = 0.0
+    log_kind: int = L.LOG_DB10
+    amin: float = 1e-10
+    ref: float = 1.0
+    ln_offset: float = 0.0
+    pcm_kind: int = L.PCM_F32
+    pcm_divisor: float = 32767.0
+
+    def to_c(self) -> L.FrontendCfg:
+        return L.FrontendCfg(self.sample_rate, self.n_fft, self.win_length, self.hop, int(self.center), self.pad_mode,
+                             self.win_align, self.tail_min_samples, self.tail_hop_samples, self.spectrum,
+                             self.mel_kind, self.n_mels, self.fmin, self.fmax, self.log_kind, self.amin, self.ref,
+                             self.ln_offset, self.pcm_kind, self.pcm_divisor)
+
+    @property
+    def n_bins(self) -> int:
+        return self.n_fft // 2 + 1
+
+    # ---- the reference's four flavours ----------------------------------------------------------------
+    @staticmethod
+    def htsat(sample_rate=32000, window_size=1024, hop_size=320, mel_bins=64, fmin=50, fmax=14000, **kw):
+        """external/hts_audio_transformer/config.py:53-59 + model/htsat.py:445-459."""
+        return FrontendConfig(sample_rate, window_size, window_size, hop_size, True, L.PAD_REFLECT, n_mels=mel_bins,
+                              fmin=float(fmin), fmax=float(fmax), log_kind=L.LOG_DB10, amin=1e-10, ref=1.0, **kw)
+
+    @staticmethod
+    def yamnet(**kw):
+        """google/yamnet/1 feature parameters (16 kHz, 25/10 ms, 64 mel 125..7500 Hz, log offset 0.001)."""
+        return FrontendConfig(16000, 512, 400, 160, False, L.PAD_NONE, L.WIN_LEFT, 15600, 7680, L.SPEC_MAGNITUDE,
+                              L.MEL_HTK_TF, 64, 125.0, 7500.0, L.LOG_LN, ln_offset=0.001, **kw)
+
+    @staticmethod
+    def crnn(sr=44100, nfft=2048, nb_mel=40, hop_len=1024, **kw):
+        """src/models/crnn/process_audio.py:29-34 as called at :94 (librosa >= 0.10 pads with zeros)."""
+        return FrontendConfig(sr, nfft, nfft, hop_len, True, L.PAD_CONSTANT, spectrum=L.SPEC_MAGNITUDE,
+                              n_mels=nb_mel, fmin=0.0, fmax=sr / 2.0, log_kind=L.LOG_LN, ln_offset=1e-9, **kw)
+
+    @staticmethod
+    def db_mel(sr=44100, n_fft=2048, hop_length=512, n_mels=64, **kw):
+        """src/utils/audio_to_spectrograms.py:30-44 (the per-clip max/top_db pass is applied by the caller)."""
+        return FrontendConfig(sr, n_fft, n_fft, hop_length, True, L.PAD_CONSTANT, n_mels=n_mels, fmin=0.0,
+                              fmax=float(sr // 2), log_kind=L.LOG_DB10, amin=1e-10, ref=1.0, **kw)
+
+
+def mel_filterbank(cfg: FrontendConfig) -> torch.Tensor:
+    """(F, n_mels) fp32 CPU tensor: the matrix logmel_extractor.melW holds (host-side table builder)."""
+    out = np.empty((cfg.n_bins, cfg.n_mels), dtype=np.float32)
+    L.check(L.lib.sed_mel_filterbank(cfg.mel_kind, cfg.sample_rate, cfg.n_fft, cfg.n_mels, cfg.fmin, cfg.fmax,
+                                     out.ctypes.data), "sed_mel_filterbank")
+    return torch.from_numpy(out)
+
+
+def hann_window(n_fft: int, win_length: int, win_align: int = L.WIN_CENTER) -> torch.Tensor:
+    out = np.empty(n_fft, dtype=np.float32)
+    L.check(L.lib.sed_hann_window(n_fft, win_length, win_align, out.ctypes.data), "sed_hann_window")
+    return torch.from_numpy(out)
+
+
+class _Plan:
+    """Owns one sed_plan on one device."""
+
+    def __init__(self, cfg: FrontendConfig, device: torch.device):
+        self.cfg, self.device = cfg, device
+        self.ptr = C.c_void_p()
+        c = cfg.to_c()
+        with torch.cuda.device(device):
+            L.check(L.lib.sed_plan_create(C.byref(c), C.byref(self.ptr)), "sed_plan_create")
+
+    def num_frames(self, n_samples: int) -> int:
+        t = int(L.lib.sed_plan_num_frames(self.ptr, int(n_samples)))
+        L.check(t, "sed_plan_num_frames")
+        return t
+
+    def set_mel_weights(self, melW: torch.Tensor) -> None:
+        w = melW.detach().to("cpu", torch.float32).contiguous()
+        if tuple(w.shape) != (self.cfg.n_bins, self.cfg.n_mels):
+            raise ValueError(f"melW must be {(self.cfg.n_bins, self.cfg.n_mels)}, got {tuple(w.shape)}")
+        with torch.cuda.device(self.device):
+            L.check(L.lib.sed_plan_set_mel_weights(self.ptr, w.data_ptr()), "sed_plan_set_mel_weights")
+
+    def set_affine(self, scale: Optional[torch.Tensor], shift: Optional[torch.Tensor]) -> None:
+        with torch.cuda.device(self.device):
+            if scale is None:
+                L.check(L.lib.sed_plan_set_affine(self.ptr, None, None), "sed_plan_set_affine")
+                return
+            s = scale.detach().to("cpu", torch.float32).contiguous()
+            b = shift.detach().to("cpu", torch.float32).contiguous()
+            if s.numel() != self.cfg.n_mels or b.numel() != self.cfg.n_mels:
+                raise ValueError("affine scale/shift must have n_mels elements")
+            L.check(L.lib.sed_plan_set_affine(self.ptr, s.data_ptr(), b.data_ptr()), "sed_plan_set_affine")
+
+    def __deepcopy__(self, memo):
+        return None  # plans are per-process device objects; a copied module builds its own on first use
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                L.lib.sed_plan_destroy(self.ptr)
+                self.ptr = C.c_void_p()
+        except Exception:
+            pass
+
+
+def _require_cuda(x: torch.Tensor, what: str) -> None:
+    if not x.is_cuda:
+        raise RuntimeError(f"{what}: input is on {x.device}; the front-end runs only on a ROCm device (no CPU path)")
+
+
+def _prep_pcm(x: torch.Tensor, cfg: FrontendConfig) -> torch.Tensor:
+    want = torch.int16 if cfg.pcm_kind == L.PCM_I16 else torch.float32
+    if x.dim() != 2:
+        raise RuntimeError(f"expected a (batch, samples) tensor, got shape {tuple(x.shape)}")
+    if x.dtype != want:
+        raise RuntimeError(f"expected dtype {want}, got {x.dtype}")
+    if x.stride(1) != 1 or x.stride(0) < x.shape[1]:
+        x = x.contiguous()
+    return x
+
+
+class _PlanHolder(nn.Module):
+    """Lazily creates one plan per device and keeps it in step with the module's tables."""
+
+    def __init__(self):
+        super().__init__()
+        self._plans = {}
+
+    def _cfg(self) -> FrontendConfig:
+        raise NotImplementedError
+
+    def _sync_plan(self, plan: _Plan) -> None:
+        """Hook: push module tables (mel matrix, affine) into a fresh or stale plan."""
+
+    def _tables_version(self):
+        return None
+
+    def _plan_for(self, device: torch.device) -> _Plan:
+        key = device.index if device.index is not None else torch.cuda.current_device()
+        ent = self._plans.get(key)
+        ver = self._tables_version()
+        if ent is None or ent[0] is None or ent[1] != ver:
+            plan = ent[0] if ent is not None and ent[0] is not None else _Plan(self._cfg(), torch.device("cuda", key))
+            self._sync_plan(plan)
+            self._plans[key] = (plan, ver)
+            return plan
+        return ent[0]
+
+
+def _run_front(plan: _Plan, x: torch.Tensor, spectrogram: bool) -> torch.Tensor:
+    cfg = plan.cfg
+    B, n = x.shape
+    T = plan.num_frames(n)
+    row = cfg.n_bins if spectrogram else cfg.n_mels
+    out = torch.empty((B, T, row), dtype=torch.float32, device=x.device)
+    if B == 0 or T == 0:
+        return out
+    fn = L.lib.sed_spectrogram_forward if spectrogram else L.lib.sed_logmel_forward
+    with torch.cuda.device(x.device):
+        L.check(fn(plan.ptr, x.data_ptr(), B, n, x.stride(0), out.data_ptr(), T * row, L.stream_ptr(x.device)),
+                "sed_spectrogram_forward" if spectrogram else "sed_logmel_forward")
+    return out
+
+
+class _ConvWeight(nn.Module):
+    """Holder for a frozen `weight` so that state_dict keys match torchlibrosa's conv_real / conv_imag."""
+
+    def __init__(self, w: torch.Tensor):
+        super().__init__()
+        self.weight = nn.Parameter(w, requires_grad=False)
+
+
+class _STFTTables(nn.Module):
+    def __init__(self, n_fft: int, window_full: torch.Tensor):
+        super().__init__()
+        n = torch.arange(n_fft, dtype=torch.float64)
+        k = torch.arange(n_fft // 2 + 1, dtype=torch.float64)
+        ang = -2.0 * math.pi * torch.remainder(torch.outer(k, n), n_fft) / n_fft
+        w = window_full.to(torch.float64)[None, :]
+        self.conv_real = _ConvWeight((torch.cos(ang) * w).to(torch.float32)[:, None, :].contiguous())
+        self.conv_imag = _ConvWeight((torch.sin(ang) * w).to(torch.float32)[:, None, :].contiguous())
+
+
+class Spectrogram(_PlanHolder):
+    """torchlibrosa.stft.Spectrogram: (B, L) -> (B, 1, T, n_fft//2+1), power spectrogram by default.
+
+    The state_dict carries stft.conv_real.weight / stft.conv_imag.weight (F, 1, n_fft) like the reference
+    module, so checkpoints saved from it load with strict=True; the kernels use their own twiddle tables and
+    the loaded tensors are only checked for agreement with the analytic windowed DFT matrix.
+    """
+
+    def __init__(self, n_fft=2048, hop_length=None, win_length=None, window="hann", center=True, pad_mode="reflect",
+                 power=2.0, freeze_parameters=True):
+        super().__init__()
+        assert pad_mode in ["constant", "reflect"]
+        if window != "hann":
+            raise ValueError("only the 'hann' window is built")
+        self.n_fft = n_fft
+        self.win_length = n_fft if win_length is None else win_length
+        self.hop_length = int(self.win_length // 4) if hop_length is None else hop_length
+        self.center, self.pad_mode, self.power = center, pad_mode, power
+        self.stft = _STFTTables(n_fft, hann_window(n_fft, self.win_length))
+        self.register_load_state_dict_post_hook(_check_stft_tables)
+
+    def _cfg(self) -> FrontendConfig:
+        return FrontendConfig(1, self.n_fft, self.win_length, self.hop_length, bool(self.center),
+                              L.PAD_REFLECT if self.pad_mode == "reflect" else L.PAD_CONSTANT,
+                              spectrum=L.SPEC_MAGNITUDE if self.power == 1.0 else L.SPEC_POWER, n_mels=1,
+                              fmin=0.0, fmax=0.5, log_kind=L.LOG_NONE)
+
+    @torch.no_grad()
+    def forward(self, input: torch.Tensor) -> torch.Tensor:
+        _require_cuda(input, "Spectrogram")
+        cfg = self._cfg()
+        x = _prep_pcm(input, cfg)
+        out = _run_front(self._plan_for(x.device), x, spectrogram=True)
+        if self.power not in (1.0, 2.0):
+            out = out ** (self.power / 2.0)
+        return out[:, None, :, :]
+
+
+def _check_stft_tables(module, incompatible_keys):
+    ref = _STFTTables(module.n_fft, hann_window(module.n_fft, module.win_length))
+    for name in ("conv_real", "conv_imag"):
+        got = getattr(module.stft, name).weight.detach().cpu()
+        if not torch.allclose(got, getattr(ref, name).weight, atol=1e-5, rtol=0):
+            raise RuntimeError(f"loaded stft.{name}.weight is not the Hann-windowed DFT matrix this module computes")
+
+
+class LogmelFilterBank(_PlanHolder):
+    """torchlibrosa.stft.LogmelFilterBank: (..., T, F) power spectrogram -> (..., T, n_mels) log-mel."""
+
+    def __init__(self, sr=22050, n_fft=2048, n_mels=64, fmin=0.0, fmax=None, is_log=True, ref=1.0, amin=1e-10,
+                 top_db=80.0, freeze_parameters=True):
+        super().__init__()
+        self.sr, self.n_fft, self.n_mels = sr, n_fft, n_mels
+        self.fmin = fmin
+        self.fmax = sr // 2 if fmax is None else fmax
+        self.is_log, self.ref, self.amin, self.top_db = is_log, ref, amin, top_db
+        if top_db is not None and top_db < 0:
+            raise ValueError("top_db must be non-negative")
+        self.melW = nn.Parameter(mel_filterbank(self._cfg()), requires_grad=False)
+
+    def _cfg(self) -> FrontendConfig:
+        return FrontendConfig(int(self.sr), self.n_fft, self.n_fft, self.n_fft // 4, n_mels=self.n_mels,
+                              fmin=float(self.fmin), fmax=float(self.fmax),
+                              log_kind=L.LOG_DB10 if self.is_log else L.LOG_NONE, amin=float(self.amin),
+                              ref=float(self.ref))
+
+    def _tables_version(self):
+        return self.melW._version
+
+    def _sync_plan(self, plan: _Plan) -> None:
+        plan.set_mel_weights(self.melW)
+
+    @torch.no_grad()
+    def forward(self, input: torch.Tensor) -> torch.Tensor:
+        _require_cuda(input, "LogmelFilterBank")
+        if input.shape[-1] != self.n_fft // 2 + 1:
+            raise RuntimeError(f"last dimension must be {self.n_fft // 2 + 1}, got {input.shape[-1]}")
+        x = input.to(torch.float32).contiguous()
+        rows = x.numel() // x.shape[-1]
+        out = torch.empty(x.shape[:-1] + (self.n_mels,), dtype=torch.float32, device=x.device)
+        plan = self._plan_for(x.device)
+        with torch.cuda.device(x.device):
+            s = L.stream_ptr(x.device)
+            L.check(L.lib.sed_mel_from_spectrogram(plan.ptr, x.data_ptr(), rows, out.data_ptr(), s),
+                    "sed_mel_from_spectrogram")
+            if self.is_log and self.top_db is not None:
+                L.check(L.lib.sed_db_normalize(out.data_ptr(), 1, out.numel(), 0, float(self.top_db), s),
+                        "sed_db_normalize")
+        return out
+
+
+class LogMelFrontend(_PlanHolder):
+    """Fused front-end: waveform (B, L) -> log-mel, one kernel launch.
+
+    layout: 'b1tm' (B, 1, T, M) as HTS-AT consumes it, 'btm' (B, T, M), 'bmt' (B, M, T) as librosa returns it.
+    An optional per-mel affine (eval-mode BatchNorm over mel bins, or a fitted StandardScaler) is applied in the
+    kernel's epilogue.
+    """
+
+    def __init__(self, cfg: FrontendConfig, layout: str = "b1tm", melW: Optional[torch.Tensor] = None):
+        super().__init__()
+        if layout not in ("b1tm", "btm", "bmt"):
+            raise ValueError(layout)
+        self.cfg, self.layout = cfg, layout
+        self.melW = nn.Parameter(mel_filterbank(cfg) if melW is None else melW.detach().clone().float().cpu(),
+                                 requires_grad=False)
+        self.register_buffer("affine_scale", None)
+        self.register_buffer("affine_shift", None)
+        self._affine_version = 0
+
+    @classmethod
+    def from_torchlibrosa(cls, spectrogram_extractor: Spectrogram, logmel_extractor: LogmelFilterBank,
+                          layout: str = "b1tm") -> "LogMelFrontend":
+        """Fuse a Spectrogram + LogmelFilterBank pair (as held by HTSAT_Swin_Transformer) into one module."""
+        s, m = spectrogram_extractor, logmel_extractor
+        if s.power != 2.0 or not m.is_log or m.top_db is not None or s.n_fft != m.n_fft:
+            raise ValueError("only power=2.0, is_log=True, top_db=None pairs with equal n_fft can be fused")
+        cfg = FrontendConfig(int(m.sr), s.n_fft, s.win_length, s.hop_length, bool(s.center),
+                             L.PAD_REFLECT if s.pad_mode == "reflect" else L.PAD_CONSTANT, n_mels=m.n_mels,
+                             fmin=float(m.fmin), fmax=float(m.fmax), log_kind=L.LOG_DB10, amin=float(m.amin),
+                             ref=float(m.ref))
+        return cls(cfg, layout, melW=m.melW)
+
+    def set_affine(self, scale: Optional[torch.Tensor], shift: Optional[torch.Tensor]) -> None:
+        self.affine_scale = None if scale is None else scale.detach().clone().float()
+        self.affine_shift = None if shift is None else shift.detach().clone().float()
+        self._affine_version += 1
+
+    def set_batchnorm(self, bn: nn.BatchNorm2d) -> None:
+        """Fold an eval-mode BatchNorm2d over mel bins (htsat.py:463,767-769) into the epilogue."""
+        inv = torch.rsqrt(bn.running_var.detach().float() + bn.eps)
+        g = bn.weight.detach().float() if bn.affine else torch.ones_like(inv)
+        b = bn.bias.detach().float() if bn.affine else torch.zeros_like(inv)
+        self.set_affine(g * inv, b - bn.running_mean.detach().float() * g * inv)
+
+    def _cfg(self) -> FrontendConfig:
+        return self.cfg
+
+    def _tables_version(self):
+        return (self.melW._version, self._affine_version)
+
+    def _sync_plan(self, plan: _Plan) -> None:
+        plan.set_mel_weights(self.melW)
+        plan.set_affine(self.affine_scale, self.affine_shift)
+
+    def num_frames(self, n_samples: int, device=None) -> int:
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        return self._plan_for(dev).num_frames(n_samples)
+
+    @torch.no_grad()
+    def forward(self, input: torch.Tensor) -> torch.Tensor:
+        _require_cuda(input, "LogMelFrontend")
+        x = _prep_pcm(input, self.cfg)
+        out = _run_front(self._plan_for(x.device), x, spectrogram=False)
+        if self.layout == "b1tm":
+            return out[:, None, :, :]
+        if self.layout == "bmt":
+            return out.transpose(1, 2)
+        return out
+
+
+class _Identity(nn.Module):
+    def forward(self, x):
+        return x
+
+
+def install_fused_frontend(model: nn.Module) -> nn.Module:
+    """Swap model.spectrogram_extractor / model.logmel_extractor (the attributes HTSAT_Swin_Transformer.forward
+    calls at htsat.py:763-764) for the fused kernel + an identity, leaving forward() untouched."""
+    fused = LogMelFrontend.from_torchlibrosa(model.spectrogram_extractor, model.logmel_extractor)
+    model.spectrogram_extractor = fused
+    model.logmel_extractor = _Identity()
+    return model
+
+
+# ---- functional forms of the other flavours --------------------------------------------------------------
+
+_FUNCTIONAL = {}
+
+
+def _functional(cfg: FrontendConfig, layout: str) -> LogMelFrontend:
+    key = (cfg, layout)
+    if key not in _FUNCTIONAL:
+        _FUNCTIONAL[key] = LogMelFrontend(cfg, layout)
+    return _FUNCTIONAL[key]
+
+
+def _as_cuda_batch(y, dtype=torch.float32):
+    t = torch.as_tensor(y)
+    squeeze = t.dim() == 1
+    if squeeze:
+        t = t[None]
+    if not t.is_cuda:
+        if not torch.cuda.is_available():
+            raise RuntimeError("no ROCm device is visible; the front-end has no CPU path")
+        t = t.to("cuda")
+    return t.to(dtype), squeeze
+
+
+def yamnet_log_mel(waveform):
+    """(L,) or (B, L) fp32 16 kHz mono in [-1, 1] -> (log_mel (B, T, 64), patches (B, N, 96, 64)).
+
+    patches are overlapping views (0.96 s window, 0.48 s hop) of log_mel, not copies.
+    """
+    x, squeeze = _as_cuda_batch(waveform)
+    lm = _functional(FrontendConfig.yamnet(), "btm")(x)
+    patches = lm.unfold(1, 96, 48).permute(0, 1, 3, 2) if lm.shape[1] >= 96 else lm.new_empty((lm.shape[0], 0, 96, 64))
+    if squeeze:
+        return lm[0], patches[0]
+    return lm, patches
+
+
+def extract_mbe(_y, _sr, _nfft, _nb_mel, _hop_len):
+    """Log mel-band energies, (n_mels, T) (or (B, n_mels, T) for a batch); numpy in -> numpy out."""
+    x, squeeze = _as_cuda_batch(_y)
+    out = _functional(FrontendConfig.crnn(int(_sr), int(_nfft), int(_nb_mel), int(_hop_len)), "bmt")(x)
+    if squeeze:
+        out = out[0]
+    return out.cpu().numpy() if not torch.is_tensor(_y) else out
+
+
+def get_mel_spec_db(y, sr, n_fft=2048, hop_length=512, n_mels=64, top_db=80.0):
+    """Power mel in dB relative to the clip's maximum, floored at -top_db: (n_mels, T) / (B, n_mels, T)."""
+    x, squeeze = _as_cuda_batch(y)
+    fe = _functional(FrontendConfig.db_mel(int(sr), n_fft, hop_length, n_mels), "btm")
+    out = fe(x)
+    with torch.cuda.device(out.device):
+        L.check(L.lib.sed_db_normalize(out.data_ptr(), out.shape[0], out.shape[1] * out.shape[2], 1, float(top_db),
+                                       L.stream_ptr(out.device)), "sed_db_normalize")
+    out = out.transpose(1, 2)
+    if squeeze:
+        out = out[0]
+    return out.cpu().numpy() if not torch.is_tensor(y) else out

@@ -1,0 +1,219 @@
+"""GPU parity: the HIP decoders (through the C ABI) against the golden fixtures generated from the reference
+and against the CPU oracle on seeded inputs.  Everything here is bit exact."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import decode as od
+
+pytestmark = pytest.mark.gpu
+
+CLASSES = ["cough", "dog_bark", "gun_shot", "siren", "car_horn"]
+NAMES6 = CLASSES + ["non_event"]
+
+
+def _events(pack, prefix, files, labels):
+    out = {f: [] for f in files}
+    for fi, li, on, off in zip(pack[prefix + "_fi"], pack[prefix + "_li"], pack[prefix + "_on"], pack[prefix + "_off"]):
+        f = files[int(fi)]
+        out[f].append({"file": f, "event_onset": float(on), "event_offset": float(off), "event_label": labels[int(li)]})
+    return out
+
+
+@pytest.fixture(scope="module")
+def kat(golden_dir):
+    pack = np.load(os.path.join(golden_dir, "crnn_kat.npz"))
+    return pack, [str(f) for f in pack["files"]], [str(l) for l in pack["labels"]]
+
+
+@pytest.mark.parametrize("thr", ["0.3", "0.6", "1.0"])
+def test_merge_kat(kat, thr):
+    import sed_amd
+    pack, files, labels = kat
+    raw = _events(pack, "raw", files, labels)
+    want = _events(pack, "m" + thr, files, labels)
+    got = sed_amd.merge_close_events_batch(raw, float(thr))
+    assert got == want and list(got) == files
+    for f in files[:25] + files[-5:]:
+        assert sed_amd.merge_close_events(raw[f], float(thr)) == want[f]
+    assert sed_amd.merge_close_events([], 0.5) == []
+
+
+def test_merge_random_overlapping_and_long_groups():
+    import sed_amd
+    rng = np.random.default_rng(3)
+    data = {}
+    for i in range(200):
+        n = int(rng.integers(0, 400 if i % 20 == 0 else 40))
+        on = np.round(rng.uniform(0, 60, n), 3)
+        dur = np.round(rng.exponential(0.4, n) - (0.2 if i % 7 == 0 else 0.0), 3)   # some negative durations
+        data[f"f{i}"] = [{"file": f"f{i}", "event_onset": float(a), "event_offset": float(a + d),
+                          "event_label": str(rng.integers(0, 3)), "extra": k}
+                         for k, (a, d) in enumerate(zip(on, dur))]
+    for thr in (0.0, 0.3, 0.5, 2.0):
+        got = sed_amd.merge_close_events_batch(data, thr)
+        want = {k: od.merge_close_events(v, thr) for k, v in data.items()}
+        assert got == want, thr
+
+
+def test_decode_predictions_roundtrip(kat, golden_dir):
+    import sed_amd
+    pack, files, labels = kat
+    a = np.load(os.path.join(golden_dir, "crnn_activity.npz"))
+    T = int(a["T"])
+    act = np.unpackbits(a["act"], axis=1)[:, :T, :].astype(int)
+    idx_to_label = dict(enumerate(labels))
+    assert sed_amd.decode_predictions(act, files, idx_to_label, 43) == _events(pack, "raw", files, labels)
+    cur = sed_amd.decode_predictions(act, files, idx_to_label, 43.06640625)
+    assert np.array_equal([e["event_onset"] for f in files for e in cur[f]], a["fps_cur_on"])
+    assert np.array_equal([e["event_offset"] for f in files for e in cur[f]], a["fps_cur_off"])
+    # more predictions than names, numpy-str names, non-binary activity
+    few = sed_amd.decode_predictions(act[:3], np.asarray(files[:2]), idx_to_label, 43)
+    assert list(few) == files[:2]
+    weird = np.array([[[0], [2], [3], [3], [2], [0], [1], [0]]])
+    assert sed_amd.decode_predictions(weird, ["w"], {0: "x"}, 10) == od.decode_predictions(weird, ["w"], {0: "x"}, 10)
+
+
+def test_full_crnn_chain_on_synthetic_probabilities(kat):
+    """D2 + D3 + D4 at BASELINE config 3 size (500 x 862 x 5) against the oracle."""
+    import sed_amd
+    from scipy.ndimage import gaussian_filter1d
+    rng = np.random.default_rng(21)
+    probs = 1.0 / (1.0 + np.exp(-4.0 * gaussian_filter1d(rng.standard_normal((500, 862, 5)), 6.0, axis=1) / 0.25))
+    probs = probs.astype(np.float32)
+    files = [f"clip_{i:04d}.wav" for i in range(500)]
+    idx_to_label = {0: "car_horn", 1: "cough", 2: "dog_bark", 3: "siren", 4: "gun_shot"}
+    fps = 44100 / 1024
+    got = sed_amd.decode_probabilities(probs, files, idx_to_label, fps, 0.5)
+    want = od.decode_predictions(od.smooth_and_threshold(probs, 0.5), files, idx_to_label, fps)
+    assert got == want
+    n_ev = sum(len(v) for v in want.values())
+    assert n_ev > 2000
+    for thr in (0.3, 0.6, 1.0):
+        assert sed_amd.merge_close_events_batch(got, thr) == {k: od.merge_close_events(v, thr) for k, v in want.items()}
+
+
+def test_gaussian_threshold_bits_near_the_threshold(golden_dir):
+    """Traces built to sit within a few ulp of 0.5 after smoothing: the activity must match scipy's bits."""
+    import sed_amd
+    from sed_amd import decode as D
+    z = np.load(os.path.join(golden_dir, "d2_vectors.npz"))
+    x, y = z["x"], z["y"]
+    dev = torch.device("cuda", 0)
+    for thr in (0.5, float(np.median(y)), float(y[0, 100, 2]), float(np.nextafter(y[3, 400, 1], np.float32(2)))):
+        runs, counts = D.threshold_runs(torch.from_numpy(x).to(dev), thr, "gauss")
+        runs, counts = runs.cpu().numpy(), counts.cpu().numpy()
+        act = (y > np.float32(thr)).astype(int)
+        for b in range(x.shape[0]):
+            for c in range(x.shape[2]):
+                want = od.contiguous_regions(act[b, :, c])
+                assert [tuple(r) for r in runs[b, c, :counts[b, c]]] == want, (thr, b, c)
+
+
+def test_detect_onsets_offsets_vectors(golden_dir):
+    import sed_amd
+    exp = json.load(open(os.path.join(golden_dir, "d1_vectors.json")))["cases"]
+    inp = np.load(os.path.join(golden_dir, "decode_inputs.npz"))
+    for i, rec in enumerate(exp):
+        p = inp[f"d1_{i}"]
+        for mf in (1, 0):
+            on, off = sed_amd.detect_onsets_offsets(p, 0.5, 0.48, bool(mf))
+            assert on.dtype == np.float64 or on.size == 0
+            assert [float(v).hex() for v in np.atleast_1d(on)] == rec[f"on_{mf}"], (i, mf)
+            assert [float(v).hex() for v in np.atleast_1d(off)] == rec[f"off_{mf}"], (i, mf)
+
+
+def test_detect_batch_4096_streams():
+    """BASELINE config 4 size: 4096 concurrent 10 s detector streams (20 patches each)."""
+    import sed_amd
+    rng = np.random.default_rng(31)
+    p = rng.random((4096, 20), dtype=np.float32)
+    p[::5] = (p[::5] > 0.5).astype(np.float32)
+    got = sed_amd.detect_onsets_offsets_batch(p, 0.5, 0.48, True)
+    for b in range(4096):
+        on, off = od.detect_onsets_offsets(p[b], 0.5, 0.48, True)
+        assert np.array_equal(got[b][0], on) and np.array_equal(got[b][1], off), b
+
+
+def test_htsat_events_vectors(golden_dir):
+    import sed_amd
+
+    class Cfg:
+        clip_duration = 20.0
+
+    exp = json.load(open(os.path.join(golden_dir, "d5_vectors.json")))
+    inp = np.load(os.path.join(golden_dir, "decode_inputs.npz"))
+    for i, rec in enumerate(exp):
+        batch = {"file": rec["files"], "pred_map": torch.from_numpy(inp[f"d5_{i}"])}
+        assert sed_amd.get_events_from_batch(batch, Cfg) == rec["expected"], i
+    batches = [{"file": exp[i]["files"], "pred_map": torch.from_numpy(inp[f"d5_{i}"])} for i in range(len(exp))]
+    merged = {}
+    for rec in exp:
+        merged = merged | rec["expected"]
+    assert sed_amd.get_events(batches, Cfg) == merged
+
+
+def test_yamnet_frame_events_vectors(golden_dir):
+    import sed_amd
+    exp = json.load(open(os.path.join(golden_dir, "d6_vectors.json")))
+    inp = np.load(os.path.join(golden_dir, "decode_inputs.npz"))
+    for i, rec in enumerate(exp):
+        for mf in (1, 0):
+            got = sed_amd.predict_events(inp[f"d6_{i}"], f"/data/x/clip_{i}.wav", CLASSES, 0.48, bool(mf))
+            assert got == rec[f"expected_{mf}"], (i, mf)
+
+
+def test_htsat_clip_label_vectors(golden_dir):
+    import sed_amd
+    exp = json.load(open(os.path.join(golden_dir, "d7_vectors.json")))
+    inp = np.load(os.path.join(golden_dir, "decode_inputs.npz"))
+    for i, rec in enumerate(exp):
+        assert sed_amd.get_classification_label(inp[f"d7_{i}"], NAMES6) == rec["label"], i
+
+
+def test_argmax_runs_random_against_oracle():
+    import sed_amd
+    rng = np.random.default_rng(41)
+    for T in (1, 2, 63, 64, 65, 128, 4096):
+        pm = rng.random((3, T, 6)).astype(np.float32)
+        lab = np.repeat(rng.integers(0, 6, T // 5 + 1), 5)[:T]
+        pm[:, np.arange(T), lab] += 0.6
+
+        class Cfg:
+            clip_duration = 20.0
+        for b in range(3):
+            names = [f"c{b}.wav"]
+            got = sed_amd.get_events_from_batch({"file": names, "pred_map": pm[b:b + 1]}, Cfg)
+            assert got == od.htsat_events_from_batch(names, pm[b:b + 1], NAMES6, 5, 20.0), (T, b)
+            for mf in (True, False):
+                assert sed_amd.predict_events(pm[b], names[0], CLASSES, 0.48, mf) == \
+                    od.yamnet_frame_events(pm[b], names[0], CLASSES, 0.48, mf), (T, b, mf)
+            assert sed_amd.get_classification_label(pm[b], NAMES6) == NAMES6[od.htsat_clip_label(pm[b])]
+
+
+def test_frame_run_merge_matches_time_merge():
+    """sed_merge_runs (frame indices + host time table) gives the same events as merging the formatted times."""
+    import sed_amd
+    from sed_amd import decode as D
+    rng = np.random.default_rng(51)
+    from scipy.ndimage import gaussian_filter1d
+    probs = (1.0 / (1.0 + np.exp(-16.0 * gaussian_filter1d(rng.standard_normal((64, 862, 5)), 5.0, axis=1)))).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    runs, counts = D.threshold_runs(torch.from_numpy(probs).to(dev), 0.5, "gauss")
+    fps = 44100 / 1024
+    table = torch.tensor([round(k * (1.0 / fps), 3) for k in range(863)], dtype=torch.float64, device=dev)
+    labels = {0: "car_horn", 1: "cough", 2: "dog_bark", 3: "siren", 4: "gun_shot"}
+    files = [f"f{i}" for i in range(64)]
+    events = sed_amd.decode_probabilities(probs, files, labels, fps, 0.5)
+    for gap in (0.3, 0.6, 1.0):
+        mr, mc = D.merge_runs(runs, counts, table, gap)
+        mr, mc = mr.cpu().numpy(), mc.cpu().numpy()
+        tt = table.cpu().numpy()
+        for i, f in enumerate(files):
+            got = sorted(((float(tt[s]), float(tt[e]), labels[c]) for c in range(5) for s, e in mr[i, c, :mc[i, c]]),
+                         key=lambda t: t[0])
+            want = [(e["event_onset"], e["event_offset"], e["event_label"]) for e in od.merge_close_events(events[f], gap)]
+            assert sorted(got) == sorted(want), (gap, f)

@@ -1,0 +1,243 @@
+"""GPU parity: the HIP front-end (through the C ABI) against the CPU oracle on the same seeded audio.
+
+Tolerance (fp32 data path, fp64 gold): |hip - gold| <= 1e-3 in the log-mel domain on every mel bin within
+60 dB of its frame's peak; on deeper bins the HIP error must not exceed max(1e-3, 1.5 x the error of the
+reference's own fp32 conv-DFT formulation against the same gold).  Exact-silence frames equal the floor.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import frontend as of
+
+pytestmark = pytest.mark.gpu
+
+NEAR_DB = 60.0
+
+
+def _dev():
+    import sed_amd  # noqa: F401  (fails loudly if the extension is missing)
+    assert torch.cuda.is_available()
+    return torch.device("cuda", 0)
+
+
+def _check(hip, gold, ref32, near_span, tol=1e-3):
+    hip, gold, ref32 = np.asarray(hip, np.float64), np.asarray(gold, np.float64), np.asarray(ref32, np.float64)
+    assert hip.shape == gold.shape
+    peak = gold.max(axis=-1, keepdims=True)
+    near = gold >= peak - near_span
+    err = np.abs(hip - gold)
+    rerr = np.abs(ref32 - gold)
+    near_max = float(err[near].max())
+    deep_max = float(err[~near].max()) if (~near).any() else 0.0
+    deep_ref = float(rerr[~near].max()) if (~near).any() else 0.0
+    print(f"near-bin max err {near_max:.3e} (ref32 {float(rerr[near].max()):.3e}); deep-bin {deep_max:.3e} (ref32 {deep_ref:.3e})")
+    assert near_max <= tol
+    assert deep_max <= max(tol, 1.5 * deep_ref)
+
+
+def test_htsat_fused_vs_oracle():
+    import sed_amd
+    dev = _dev()
+    x = of.synth_batch(5, 64000, 32000)
+    x[4, :] = 0.0                                                     # one clip of digital silence
+    fe = sed_amd.LogMelFrontend(sed_amd.FrontendConfig.htsat())
+    y = fe(torch.from_numpy(x).to(dev))
+    assert y.shape == (5, 1, 201, 64) and y.dtype == torch.float32 and y.is_contiguous()
+    y = y.cpu().numpy()
+    gold = of.htsat_logmel(x, mode="gold")
+    ref32 = of.htsat_logmel(x, mode="ref32")
+    _check(y[:4], gold[:4], ref32[:4], NEAR_DB)
+    assert np.all(y[4] == y[4].flat[0]) and abs(float(y[4].flat[0]) + 100.0) < 2e-5   # floor, exactly uniform
+
+
+def test_htsat_full_clip_10s():
+    import sed_amd
+    dev = _dev()
+    x = of.synth_batch(2, 320000, 32000, first=100)
+    y = sed_amd.LogMelFrontend(sed_amd.FrontendConfig.htsat())(torch.from_numpy(x).to(dev)).cpu().numpy()
+    assert y.shape == (2, 1, 1001, 64)
+    _check(y, of.htsat_logmel(x, mode="gold"), of.htsat_logmel(x, mode="ref32"), NEAR_DB)
+
+
+def test_unfused_modules_match_reference_call_pattern():
+    """Constructed and called exactly as htsat.py:453-459 / :763-764."""
+    import sed_amd
+    dev = _dev()
+    spectrogram_extractor = sed_amd.Spectrogram(n_fft=1024, hop_length=320, win_length=1024, window="hann",
+                                                center=True, pad_mode="reflect", freeze_parameters=True).to(dev)
+    logmel_extractor = sed_amd.LogmelFilterBank(sr=32000, n_fft=1024, n_mels=64, fmin=50, fmax=14000, ref=1.0,
+                                                amin=1e-10, top_db=None, freeze_parameters=True).to(dev)
+    x = of.synth_batch(3, 48000, 32000, first=7)
+    xs = spectrogram_extractor(torch.from_numpy(x).to(dev))
+    assert xs.shape == (3, 1, 151, 513)
+    gold_p = of.power_spectrogram_gold(x, 1024, 320)
+    p = xs[:, 0].cpu().numpy().astype(np.float64)
+    assert np.max(np.abs(p - gold_p) / gold_p.max(axis=-1, keepdims=True)) < 2e-6
+    xm = logmel_extractor(xs)
+    assert xm.shape == (3, 1, 151, 64)
+    gold = of.htsat_logmel(x, mode="gold")
+    _check(xm.cpu().numpy(), gold, of.htsat_logmel(x, mode="ref32"), NEAR_DB)
+    fused = sed_amd.LogMelFrontend.from_torchlibrosa(spectrogram_extractor, logmel_extractor)(torch.from_numpy(x).to(dev))
+    assert torch.max(torch.abs(fused - xm)).item() < 1e-4
+
+
+def test_logmel_top_db_and_power_variants():
+    import sed_amd
+    dev = _dev()
+    x = of.synth_batch(2, 32000, 32000, first=3)
+    xt = torch.from_numpy(x).to(dev)
+    spec = sed_amd.Spectrogram(n_fft=1024, hop_length=320)(xt)
+    lm = sed_amd.LogmelFilterBank(sr=32000, n_fft=1024, n_mels=64, fmin=50, fmax=14000, top_db=80.0)(spec)
+    mel = of.power_spectrogram_ref32(x, 1024, 320) @ of.librosa_mel(32000, 1024, 64, 50, 14000).T
+    want = of.power_to_db(mel, 1.0, 1e-10, 80.0)[:, None]
+    assert np.max(np.abs(lm.cpu().numpy() - want)) < 2e-3
+    assert abs(lm.min().item() - (lm.max().item() - 80.0)) < 1e-4
+    mag = sed_amd.Spectrogram(n_fft=1024, hop_length=320, power=1.0)(xt)
+    assert torch.max(torch.abs(mag * mag - spec) / spec.amax(-1, keepdim=True)).item() < 1e-5
+    nolog = sed_amd.LogmelFilterBank(sr=32000, n_fft=1024, n_mels=64, fmin=50, fmax=14000, is_log=False)(spec)
+    assert np.max(np.abs(nolog.cpu().numpy()[:, 0] - mel) / mel.max()) < 1e-5
+
+
+def test_yamnet_features():
+    import sed_amd
+    _dev()
+    x = of.synth_batch(3, 160000, 16000, first=20)
+    lm, patches = sed_amd.yamnet_log_mel(torch.from_numpy(x))
+    assert lm.shape == (3, 1008, 64) and patches.shape == (3, 20, 96, 64)
+    g_lm, g_p = of.yamnet_logmel(x, mode="gold")
+    r_lm, _ = of.yamnet_logmel(x, mode="ref32")
+    _check(lm.cpu().numpy(), g_lm, r_lm, NEAR_DB / 20.0 * np.log(10.0))
+    assert np.array_equal(patches.cpu().numpy(), lm.cpu().numpy()[:, np.arange(96)[None] + 48 * np.arange(20)[:, None]])
+    lm1, p1 = sed_amd.yamnet_log_mel(x[0, :50000])                       # 1-D input, tail padded to 54000
+    assert lm1.shape == (335, 64) and p1.shape == (5, 96, 64)
+    g1, _ = of.yamnet_logmel(x[0, :50000], mode="gold")
+    assert np.max(np.abs(lm1.cpu().numpy() - g1[0])) < 1e-3
+    z, _ = sed_amd.yamnet_log_mel(np.zeros(16000, np.float32))
+    assert z.shape == (96, 64) and torch.all(z == z[0, 0]) and abs(z[0, 0].item() - np.log(0.001)) < 1e-6
+
+
+def test_crnn_extract_mbe():
+    import sed_amd
+    _dev()
+    y = of.synth_clip(5, 220500, 44100)
+    mbe = sed_amd.extract_mbe(y, 44100, 2048, 40, 1024)
+    assert isinstance(mbe, np.ndarray) and mbe.shape == (40, 216) and mbe.dtype == np.float32
+    _check(mbe.T, of.crnn_extract_mbe(y, mode="gold").T, of.crnn_extract_mbe(y, mode="ref32").T,
+           NEAR_DB / 20.0 * np.log(10.0))
+    z = sed_amd.extract_mbe(np.zeros(44100, np.float32), 44100, 2048, 40, 1024)
+    assert np.all(z == z[0, 0]) and abs(float(z[0, 0]) - np.log(1e-9)) < 1e-5
+
+
+def test_db_mel_per_clip_reference():
+    import sed_amd
+    _dev()
+    y = of.synth_batch(2, 88200, 44100, first=30)
+    got = sed_amd.get_mel_spec_db(y, 44100)
+    want = of.librosa_db_mel(y, mode="gold")
+    assert got.shape == (2, 64, 173) and got.max() == 0.0 and got.min() >= -80.0
+    assert np.max(np.abs(got - want)) < 1e-3
+
+
+def test_int16_input_and_exhaustive_conversion():
+    import sed_amd
+    dev = _dev()
+    cfg16 = sed_amd.FrontendConfig.htsat(pcm_kind=1, pcm_divisor=32767.0)
+    s = of.f32_to_pcm16(of.synth_batch(2, 65536, 32000, first=40))
+    s[1] = np.arange(-32768, 32768, dtype=np.int16)                      # every int16 value once
+    y16 = sed_amd.LogMelFrontend(cfg16)(torch.from_numpy(s).to(dev))
+    yf = sed_amd.LogMelFrontend(sed_amd.FrontendConfig.htsat())(torch.from_numpy(of.pcm16_to_f32(s)).to(dev))
+    assert torch.equal(y16, yf)                                          # identical samples -> identical bits
+    with pytest.raises(RuntimeError, match="dtype"):
+        sed_amd.LogMelFrontend(cfg16)(torch.zeros(1, 4096, device=dev))
+
+
+def test_edges_ragged_short_empty_strided():
+    import sed_amd
+    dev = _dev()
+    fe = sed_amd.LogMelFrontend(sed_amd.FrontendConfig.htsat(), layout="btm")
+    for n in (513, 640, 1023, 1024, 5000, 5441, 10239, 33333):          # T = 2 .. 105, none a multiple of 16
+        x = of.synth_batch(2, n, 32000, first=n)
+        y = fe(torch.from_numpy(x).to(dev)).cpu().numpy()
+        g = of.htsat_logmel(x, mode="gold")[:, 0]
+        assert y.shape == g.shape == (2, 1 + n // 320, 64)
+        near = g >= g.max(-1, keepdims=True) - NEAR_DB
+        assert np.max(np.abs(y - g)[near]) < 1e-3, n
+    with pytest.raises(ValueError, match="too short"):
+        fe(torch.zeros(1, 512, device=dev))
+    assert fe(torch.zeros(0, 4096, device=dev)).shape == (0, 13, 64)
+    big = torch.from_numpy(of.synth_batch(3, 20001, 32000, first=9)).to(dev)
+    a = fe(big[:, 1:])                                                    # misaligned rows, row stride != length
+    b = fe(big[:, 1:].contiguous())
+    assert torch.equal(a, b)
+    assert torch.equal(fe(big[1:2, 1:]), a[1:2])                          # batch position does not matter
+
+
+def test_state_dict_and_install_on_reference_shaped_model():
+    import sed_amd
+    from torch import nn
+    dev = _dev()
+
+    class Host(nn.Module):                                               # attribute names of HTSAT_Swin_Transformer
+        def __init__(self):
+            super().__init__()
+            self.spectrogram_extractor = sed_amd.Spectrogram(n_fft=1024, hop_length=320, win_length=1024, window="hann",
+                                                             center=True, pad_mode="reflect", freeze_parameters=True)
+            self.logmel_extractor = sed_amd.LogmelFilterBank(sr=32000, n_fft=1024, n_mels=64, fmin=50, fmax=14000,
+                                                             ref=1.0, amin=1e-10, top_db=None, freeze_parameters=True)
+            self.bn0 = nn.BatchNorm2d(64)
+
+        def forward(self, x):
+            x = self.spectrogram_extractor(x)
+            x = self.logmel_extractor(x)
+            x = x.transpose(1, 3)
+            x = self.bn0(x)
+            return x.transpose(1, 3)
+
+    m = Host().to(dev).eval()
+    keys = set(m.state_dict())
+    assert {"spectrogram_extractor.stft.conv_real.weight", "spectrogram_extractor.stft.conv_imag.weight",
+            "logmel_extractor.melW"} <= keys
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    sd["bn0.running_mean"] = torch.linspace(-40, -10, 64, device=dev)
+    sd["bn0.running_var"] = torch.linspace(50, 200, 64, device=dev)
+    sd["bn0.weight"] = torch.linspace(0.5, 1.5, 64, device=dev)
+    sd["bn0.bias"] = torch.linspace(-1, 1, 64, device=dev)
+    m.load_state_dict(sd, strict=True)
+    x = torch.from_numpy(of.synth_batch(2, 32000, 32000, first=50)).to(dev)
+    want = m(x)
+    sed_amd.install_fused_frontend(m)
+    got = m(x)
+    assert got.shape == want.shape and torch.max(torch.abs(got - want)).item() < 1e-4
+    fused = m.spectrogram_extractor
+    fused.set_batchnorm(m.bn0)                                           # bn0 folded into the kernel epilogue
+    assert torch.max(torch.abs(fused(x) - want)).item() < 1e-4
+    fused.set_affine(None, None)
+
+
+def test_full_size_properties_config2():
+    """BASELINE config 2 (256 x 10 s @ 32 kHz): size-independent properties instead of a full oracle pass."""
+    import sed_amd
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    x = (0.1 * torch.randn(256, 320000, generator=g)).to(dev)
+    x[:, 100000:116000] = 0.0
+    fe = sed_amd.LogMelFrontend(sed_amd.FrontendConfig.htsat())
+    y = fe(x)
+    assert y.shape == (256, 1, 1001, 64) and torch.isfinite(y).all()
+    for b in (0, 17, 255):                                               # batch invariance, bit exact
+        assert torch.equal(fe(x[b:b + 1]), y[b:b + 1])
+    shifted = fe(x[:4, 320 * 7:])                                        # time-shift by 7 hops: interior frames equal
+    assert torch.equal(shifted[:, :, 4:900], y[:4, :, 11:907])
+    sil = y[:, 0, 316:360]                                               # frames fully inside the silent span
+    assert torch.all(sil == sil[0, 0, 0])
+    spec = sed_amd.Spectrogram(n_fft=1024, hop_length=320)(x[:8])        # Parseval on the windowed frames
+    w = sed_amd.hann_window(1024, 1024).to(dev)
+    fr = torch.nn.functional.pad(x[:8, None], (512, 512), mode="reflect")[:, 0].unfold(1, 1024, 320) * w
+    energy = (fr.double() ** 2).sum(-1)
+    s = spec[:, 0].double()
+    pars = (s[..., 0] + s[..., -1] + 2 * s[..., 1:-1].sum(-1)) / 1024
+    assert torch.max(torch.abs(pars - energy) / energy.clamp_min(1e-12)).item() < 1e-5
+    ref = of.htsat_logmel(x[250:252].cpu().numpy(), mode="gold")
+    near = ref >= ref.max(-1, keepdims=True) - NEAR_DB
+    assert np.max(np.abs(y[250:252].cpu().numpy() - ref)[near]) < 1e-3
