@@ -317,7 +317,8 @@ def synth_clip(clip_idx: int, n_samples: int, sr: int) -> np.ndarray:
     t = np.arange(n_samples) / sr
     for _ in range(2):
         f = rng.uniform(200.0, 6000.0)
-        dur = rng.uniform(0.3, min(3.0, n_samples / sr * 0.5))
+        hi = min(3.0, n_samples / sr * 0.5)
+        dur = rng.uniform(min(0.3, 0.5 * hi), hi)
         start = rng.uniform(0.0, max(1e-3, n_samples / sr - dur))
         amp = rng.uniform(0.05, 0.5)
         m = (t >= start) & (t < start + dur)
