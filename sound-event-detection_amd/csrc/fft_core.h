@@ -213,16 +213,21 @@ SED_HD void lane_xread(LaneState<G>& st, const float* xfr, int l) {
   });
 }
 
-// Bin index held in split slot s of lane l (the partner bin is NC - bin).
+// Bin index held in split slot s of lane l (the partner bin is NC - bin): l + s * lane_slot_stride(l).
+template <class G>
+SED_HD int lane_slot_stride(int l) {
+  return l == 0 ? G::R1 / 2 : G::R1;
+}
 template <class G>
 SED_HD int lane_slot_bin(int l, int s) {
-  return l == 0 ? (G::R1 / 2) * s : l + G::R1 * s;
+  return l + s * lane_slot_stride<G>(l);
 }
 
 // Stage-2 FFTs, real-FFT split and |X|^2 (or |X|) into the frame's power row pw[0..NC].
-// tw2[s*LPF + l] = W_NFFT^(lane_slot_bin(l, s)).
+// tw2[s*LPF + l] = W_NFFT^(lane_slot_bin(l, s)); slot_stride = lane_slot_stride(l), passed in so that a
+// caller inside a loop can keep the per-slot addresses from being precomputed into registers.
 template <class G, bool MAGNITUDE>
-SED_HD void lane_stage2_power(LaneState<G>& st, float* pw, const cplx* tw2, int l) {
+SED_HD void lane_stage2_power(LaneState<G>& st, float* pw, const cplx* tw2, int l, int slot_stride) {
   fft_dit<G::R2>(st.pr, st.pi);
   fft_dit<G::R2>(st.qr, st.qi);
   const bool l0 = (l == 0);
@@ -257,7 +262,7 @@ SED_HD void lane_stage2_power(LaneState<G>& st, float* pw, const cplx* tw2, int 
       pa = __builtin_sqrtf(pa);
       pb = __builtin_sqrtf(pb);
     }
-    const int k = lane_slot_bin<G>(l, s);
+    const int k = l + s * slot_stride;
     if (s < G::R2 || l0) {
       pw[k] = pa;
       pw[G::NC - k] = pb;

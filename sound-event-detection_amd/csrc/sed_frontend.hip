@@ -2,13 +2,14 @@
 // mel projection + log, one launch per batch, the (T, F) spectrogram never leaves the CU.
 //
 // Work decomposition
-//   workgroup  : WAVES wavefronts; owns a contiguous range of "tiles" (FPI consecutive frames of one clip),
-//                loops over them (persistent), tables live in LDS for the whole launch
-//   per tile   : the PCM span of the tile is staged once in LDS (every sample read once from HBM per tile,
-//                padding modes and int16 conversion resolved here), then each wavefront runs FPW frames
+//   workgroup  : WAVES wavefronts, one workgroup per CU, tables in LDS for the whole launch; after the
+//                table load there is no workgroup barrier: every wavefront streams on its own
+//   wavefront  : owns "chunks" = runs of consecutive frames of one clip and walks them FPW frames at a
+//                time.  Its LDS region holds the PCM span of the current FPW frames; the n_fft-hop samples
+//                shared with the next FPW frames stay in LDS, so every sample is fetched once per chunk
 //   per frame  : LPF lanes; see fft_core.h for the lane decomposition
-//   per wave   : exchange, power rows and mel rows use a wavefront-private LDS region, so the only
-//                workgroup barriers are the two around staging
+//   mel        : power rows are multiplied by the banded filterbank on the matrix pipe
+//                (v_mfma_f32_4x4x1_16b_f32: 16 blocks x [4 filters x 4 frames] per instruction, exact f32)
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -20,9 +21,12 @@
 
 namespace sed {
 
-using Geo512 = Geo<16, 16, 8, 4>;
-using Geo1024 = Geo<32, 16, 16, 4>;
-using Geo2048 = Geo<32, 32, 16, 2>;
+using Geo512 = Geo<16, 16, 8, 8>;
+using Geo1024 = Geo<32, 16, 16, 8>;
+using Geo2048 = Geo<32, 32, 16, 4>;
+
+constexpr int kMaxMelSets = 4;
+typedef float f4v __attribute__((ext_vector_type(4)));
 
 struct FrontParams {
   const void* pcm;
@@ -32,15 +36,19 @@ struct FrontParams {
   float pcm_div;
   int32_t n_mels, log_kind, affine;
   float amin, db_offset, ln_offset;
-  int32_t tiles_per_clip, total_tiles, tiles_per_block;
-  // LDS carve, in floats
-  int32_t off_xw, xwf, off_win, off_tw1, off_tw2, off_meta, off_melw;
-  int32_t mel_slots, mel_wcount;
+  int32_t chunk_frames, chunks_per_clip, total_chunks;
+  // per-wave LDS region, in floats: [0, span) PCM span of FPW frames; X = region + xoff holds, in turn, the
+  // exchange rows, then [power rows | mel partial sums | mel rows]
+  int32_t span, halo, fresh, reuse_halo, xoff, wave_floats;
+  // LDS carve of the shared tables, in floats
+  int32_t off_win, off_tw1, off_tw2, off_mela, off_melbase, off_quadpos, off_wave;
+  int32_t mel_sets, mel_u, mel_maxpos, n_quads;
   const float* window;
   const cplx* tw1;
   const cplx* tw2;
-  const MelEntry* meta;
-  const float* melw;
+  const float* mela;
+  const int32_t* melbase;
+  const int32_t* quadpos;
   const float* aff_scale;
   const float* aff_shift;
 };
@@ -69,91 +77,132 @@ __device__ __forceinline__ float load_padded(const T* src, int64_t s, int64_t L,
   else return (float)src[s] / div;
 }
 
-template <class G>
-__device__ __forceinline__ void stage_tile(const FrontParams& p, float* stage, int b, int t0, int nf, int tid) {
-  constexpr int NT = G::WAVES * 64;
-  const int span = (nf - 1) * p.hop + G::NFFT;
-  const int64_t s0 = (int64_t)t0 * p.hop - p.pad_left;
-  const bool interior = s0 >= 0 && s0 + span <= p.L;
-  if (p.pcm_kind == SED_PCM_F32) {
-    const float* src = (const float*)p.pcm + (int64_t)b * p.pcm_stride;
-    if (interior && p.vec_ok && (s0 & 3) == 0) {
-      const float4* s4 = (const float4*)(src + s0);
-      float4* d4 = (float4*)stage;
-      for (int i = tid; i < span / 4; i += NT) d4[i] = s4[i];
-    } else {
-      for (int i = tid; i < span; i += NT) stage[i] = load_padded<float>(src, s0 + i, p.L, p.pad_mode, 1.0f);
-    }
+// Cold path of the staging copy: clip edges (reflect / zero padding), unaligned rows.  Kept out of line so that
+// its address arithmetic is not hoisted into the streaming loop.
+__device__ __attribute__((noinline)) void stage_span_edges(const void* pcm, int pcm_kind, float div, int64_t L,
+                                                           int pad_mode, int64_t clip_off, float* dst, int64_t s0,
+                                                           int count, int lane) {
+  if (pcm_kind == SED_PCM_F32) {
+    const float* src = (const float*)pcm + clip_off;
+    for (int i = lane; i < count; i += 64) dst[i] = load_padded<float>(src, s0 + i, L, pad_mode, 1.0f);
   } else {
-    const int16_t* src = (const int16_t*)p.pcm + (int64_t)b * p.pcm_stride;
-    if (interior && p.vec_ok && (s0 & 3) == 0) {
-      const short4* s4 = (const short4*)(src + s0);
-      float4* d4 = (float4*)stage;
-      for (int i = tid; i < span / 4; i += NT) {
-        const short4 v = s4[i];
-        d4[i] = make_float4((float)v.x / p.pcm_div, (float)v.y / p.pcm_div, (float)v.z / p.pcm_div,
-                            (float)v.w / p.pcm_div);
-      }
-    } else {
-      for (int i = tid; i < span; i += NT) stage[i] = load_padded<int16_t>(src, s0 + i, p.L, p.pad_mode, p.pcm_div);
-    }
+    const int16_t* src = (const int16_t*)pcm + clip_off;
+    for (int i = lane; i < count; i += 64) dst[i] = load_padded<int16_t>(src, s0 + i, L, pad_mode, div);
   }
 }
 
-// Mel filters of one frame for lane l of its LPF-lane group: banded dot products from the power row.
-__device__ __forceinline__ void mel_project_lane(const float* pw, const MelEntry* meta, const float* melw, int slots,
-                                                 int l, float* melrow, const FrontParams& p) {
-  for (int j = 0; j < slots; ++j) {
-    const MelEntry e = meta[l * slots + j];
-    if (e.mel < 0) continue;
-    const float* x = pw + e.start;
-    const float* w = melw + e.woff;
-    float acc = 0.0f;
-    for (int i = 0; i < e.len; ++i) acc = __builtin_fmaf(x[i], w[i], acc);
-    float v = log_epilogue(acc, p.log_kind, p.amin, p.db_offset, p.ln_offset);
-    if (p.affine) v = __builtin_fmaf(v, p.aff_scale[e.mel], p.aff_shift[e.mel]);
-    melrow[e.mel] = v;
+// One wavefront copies `count` samples (multiple of 4) of clip b, starting at padded-clip sample s0, to LDS.
+__device__ __forceinline__ void stage_span(const FrontParams& p, float* dst, int64_t b, int64_t s0, int count, int lane) {
+  const bool fast = s0 >= 0 && s0 + count <= p.L && p.vec_ok;
+  if (fast && p.pcm_kind == SED_PCM_F32) {
+    const float* src = (const float*)p.pcm + b * p.pcm_stride + s0;
+    for (int i = 4 * lane; i < count; i += 256) *(float4*)(dst + i) = *(const float4*)(src + i);
+  } else if (fast) {
+    const int16_t* src = (const int16_t*)p.pcm + b * p.pcm_stride + s0;
+    for (int i = 4 * lane; i < count; i += 256) {
+      const short4 v = *(const short4*)(src + i);
+      *(float4*)(dst + i) = make_float4((float)v.x / p.pcm_div, (float)v.y / p.pcm_div, (float)v.z / p.pcm_div,
+                                        (float)v.w / p.pcm_div);
+    }
+  } else {
+    stage_span_edges(p.pcm, p.pcm_kind, p.pcm_div, p.L, p.pad_mode, b * p.pcm_stride, dst, s0, count, lane);
   }
+}
+
+// Mel projection of 4 frames (power rows prow0 + j*PITCH, j = 0..3) on the matrix pipe, then log/affine.
+// Lane 4*block + j feeds the power of frame j as the B operand and the weight of filter 4*quad + j as the
+// A operand of block `block`; after the last instruction it holds, in acc[set][i], the partial sum of filter
+// 4*quad + i for frame j over the bins of position (set, block).
+template <int PITCH>
+__device__ __forceinline__ void mel_mfma_4frames(const FrontParams& p, const float* prow0, const float* mela,
+                                                 const int32_t* melbase, const int32_t* quadpos, float* part,
+                                                 float* melrows, int lane) {
+  const int blk = lane >> 2, j = lane & 3;
+  const float* prow = prow0 + j * PITCH;
+  f4v acc[kMaxMelSets];
+  static_for<0, kMaxMelSets>([&](auto Sf) {
+    constexpr int s = decltype(Sf)::value;
+    acc[s] = f4v{0.0f, 0.0f, 0.0f, 0.0f};
+    if (s < p.mel_sets) {
+      const float* bp = prow + melbase[s * 16 + blk];
+      const float* ap = mela + ((size_t)s * p.mel_u * 64 + lane) * 4;
+      for (int u = 0; u < p.mel_u; ++u) {
+        const f4 a = ld4(ap + u * 256);
+        const f4 b = ld4(bp + 4 * u);
+        acc[s] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.x, b.x, acc[s], 0, 0, 0);
+        acc[s] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.y, b.y, acc[s], 0, 0, 0);
+        acc[s] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.z, b.z, acc[s], 0, 0, 0);
+        acc[s] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.w, b.w, acc[s], 0, 0, 0);
+      }
+    }
+  });
+  static_for<0, kMaxMelSets>([&](auto Sf) {
+    constexpr int s = decltype(Sf)::value;
+    if (s < p.mel_sets) {
+      float* d = part + (s * 16 + blk) * 16 + j;
+      d[0] = acc[s][0]; d[4] = acc[s][1]; d[8] = acc[s][2]; d[12] = acc[s][3];
+    }
+  });
+  wave_phase_fence();
+  const int n_out = 4 * p.n_mels;
+  for (int o = lane; o < n_out; o += 64) {
+    const int jj = o / p.n_mels, m = o - jj * p.n_mels;
+    const int32_t* qp = quadpos + (m >> 2) * p.mel_maxpos;
+    float acc1 = 0.0f;
+    for (int i = 0; i < p.mel_maxpos; ++i) {
+      const int pos = qp[i];
+      if (pos >= 0) acc1 += part[pos * 16 + (m & 3) * 4 + jj];
+    }
+    float v = log_epilogue(acc1, p.log_kind, p.amin, p.db_offset, p.ln_offset);
+    if (p.affine) v = __builtin_fmaf(v, p.aff_scale[m], p.aff_shift[m]);
+    melrows[jj * p.n_mels + m] = v;
+  }
+  wave_phase_fence();
 }
 
 template <class G, bool MAG, bool SPEC_OUT>
-__global__ void __launch_bounds__(G::WAVES * 64, G::WAVES == 4 ? 2 : 1) stft_mel_kernel(const FrontParams p) {
+__global__ void __launch_bounds__(G::WAVES * 64, G::WAVES == 8 ? 2 : 1) stft_mel_kernel(const FrontParams p) {
   extern __shared__ __align__(16) float smem[];
   constexpr int NT = G::WAVES * 64;
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int fi = lane / G::LPF, l = lane % G::LPF;
 
-  float* stage = smem;
-  float* xw = smem + p.off_xw + wave * p.xwf;
   float* winL = smem + p.off_win;
   cplx* tw1L = (cplx*)(smem + p.off_tw1);
   cplx* tw2L = (cplx*)(smem + p.off_tw2);
-  MelEntry* metaL = (MelEntry*)(smem + p.off_meta);
-  float* melwL = smem + p.off_melw;
+  float* melaL = smem + p.off_mela;
+  int32_t* melbaseL = (int32_t*)(smem + p.off_melbase);
+  int32_t* quadposL = (int32_t*)(smem + p.off_quadpos);
+  float* S = smem + p.off_wave + wave * p.wave_floats;
+  float* X = S + p.xoff;
 
   for (int i = tid; i < G::NFFT; i += NT) winL[i] = p.window[i];
   for (int i = tid; i < G::R1 * G::R2; i += NT) tw1L[i] = p.tw1[i];
   for (int i = tid; i < G::SLOTS * G::LPF; i += NT) tw2L[i] = p.tw2[i];
   if constexpr (!SPEC_OUT) {
-    for (int i = tid; i < G::LPF * p.mel_slots; i += NT) metaL[i] = p.meta[i];
-    for (int i = tid; i < p.mel_wcount; i += NT) melwL[i] = p.melw[i];
+    for (int i = tid; i < p.mel_sets * p.mel_u * 256; i += NT) melaL[i] = p.mela[i];
+    for (int i = tid; i < p.mel_sets * 16; i += NT) melbaseL[i] = p.melbase[i];
+    for (int i = tid; i < p.n_quads * p.mel_maxpos; i += NT) quadposL[i] = p.quadpos[i];
   }
   __syncthreads();
 
-  const int first = blockIdx.x * p.tiles_per_block;
-  const int last = min(first + p.tiles_per_block, p.total_tiles);
-  for (int tile = first; tile < last; ++tile) {
-    const int b = tile / p.tiles_per_clip;
-    const int t0 = (tile - b * p.tiles_per_clip) * G::FPI;
-    const int nf = min(G::FPI, p.T - t0);
-    stage_tile<G>(p, stage, b, t0, nf, tid);
-    __syncthreads();
-    const int wf0 = wave * G::FPW;  // first frame of this wave inside the tile
-    if (wf0 < nf) {
+  const int n_waves = gridDim.x * G::WAVES;
+  for (int chunk = blockIdx.x * G::WAVES + wave; chunk < p.total_chunks; chunk += n_waves) {
+    const int b = chunk / p.chunks_per_clip;
+    const int f_begin = (chunk - b * p.chunks_per_clip) * p.chunk_frames;
+    const int f_end = min(p.T, f_begin + p.chunk_frames);
+    for (int f0 = f_begin; f0 < f_end; f0 += G::FPW) {
+      const int64_t s0 = (int64_t)f0 * p.hop - p.pad_left;
+      if (f0 == f_begin || !p.reuse_halo) stage_span(p, S, b, s0, p.span, lane);
+      else stage_span(p, S + p.halo, b, s0 + p.halo, p.fresh, lane);
+      wave_phase_fence();
       LaneState<G> st;
-      lane_stage1<G>(st, stage + (wf0 + fi) * p.hop, winL, tw1L, l);
-      float* xfr = xw + fi * G::XFR;
+      lane_stage1<G>(st, S + fi * p.hop, winL, tw1L, l);
+      wave_phase_fence();
+      if (p.reuse_halo)  // the samples shared with the next FPW frames move to the front of the region
+        for (int i = 4 * lane; i < p.halo; i += 256) st4(S + i, ld4(S + p.fresh + i));
+      float* xfr = X + fi * G::XFR;
       lane_xwrite<G, 0>(st, xfr, l);
       wave_phase_fence();
       lane_xread<G, 0>(st, xfr, l);
@@ -162,47 +211,77 @@ __global__ void __launch_bounds__(G::WAVES * 64, G::WAVES == 4 ? 2 : 1) stft_mel
       wave_phase_fence();
       lane_xread<G, 1>(st, xfr, l);
       wave_phase_fence();
-      lane_stage2_power<G, MAG>(st, xw + fi * G::PP, tw2L, l);
+      float* pw = X + fi * G::PP;
+      int slot_stride = lane_slot_stride<G>(l);
+      asm volatile("" : "+v"(slot_stride));  // opaque: per-slot addresses are formed here, not kept in registers
+      lane_stage2_power<G, MAG>(st, pw, tw2L, l, slot_stride);
+      if (l == 0) { pw[G::NBINS] = 0.0f; pw[G::NBINS + 1] = 0.0f; pw[G::NBINS + 2] = 0.0f; }
       wave_phase_fence();
-      const int nvalid = min(G::FPW, nf - wf0);
+      const int nvalid = min(G::FPW, f_end - f0);
       if constexpr (SPEC_OUT) {
-        float* dst = p.out + (int64_t)b * p.out_stride_b + (int64_t)(t0 + wf0) * G::NBINS;
+        float* dst = p.out + (int64_t)b * p.out_stride_b + (int64_t)f0 * G::NBINS;
         for (int f = 0; f < nvalid; ++f)
-          for (int k = lane; k < G::NBINS; k += 64) dst[(int64_t)f * G::NBINS + k] = xw[f * G::PP + k];
+          for (int k = lane; k < G::NBINS; k += 64) dst[(int64_t)f * G::NBINS + k] = X[f * G::PP + k];
       } else {
-        float* melbuf = xw + G::FPW * G::PP;
-        mel_project_lane(xw + fi * G::PP, metaL, melwL, p.mel_slots, l, melbuf + fi * p.n_mels, p);
-        wave_phase_fence();
-        float* dst = p.out + (int64_t)b * p.out_stride_b + (int64_t)(t0 + wf0) * p.n_mels;
+        float* part = X + G::FPW * G::PP;
+        float* melrows = part + p.mel_sets * 256;
+        for (int g = 0; g < G::FPW / 4; ++g)
+          mel_mfma_4frames<G::PP>(p, X + 4 * g * G::PP, melaL, melbaseL, quadposL, part, melrows + 4 * g * p.n_mels, lane);
+        float* dst = p.out + (int64_t)b * p.out_stride_b + (int64_t)f0 * p.n_mels;
         const int n = nvalid * p.n_mels;
-        for (int i = lane; i < n; i += 64) dst[i] = melbuf[i];
+        for (int i = lane; i < n; i += 64) dst[i] = melrows[i];
       }
+      wave_phase_fence();
     }
-    __syncthreads();
   }
 }
 
-// Mel projection + log of a materialised spectrogram: 16 lanes per row, 16 rows per workgroup pass.
-__global__ void __launch_bounds__(256) mel_rows_kernel(const FrontParams p, const float* spec, int64_t rows, int nbins) {
+// ---- mel projection + log of a materialised spectrogram (LogmelFilterBank.forward) -------------------------
+struct MelRowsParams {
+  const float* spec;
+  float* out;
+  int64_t rows;
+  int32_t nbins, n_mels, log_kind, affine, slots, wcount;
+  float amin, db_offset, ln_offset;
+  const MelEntry* meta;
+  const float* melw;
+  const float* aff_scale;
+  const float* aff_shift;
+};
+
+// 16 lanes per row, 16 rows per workgroup pass; every lane evaluates its share of the banded filters.
+__global__ void __launch_bounds__(256) mel_rows_kernel(const MelRowsParams p) {
   extern __shared__ __align__(16) float smem[];
   const int tid = threadIdx.x;
-  const int pitch = nbins + 3;
+  const int pitch = p.nbins + 3;
   float* rowsL = smem;                                    // 16 rows
   float* melbuf = smem + 16 * pitch;                      // 16 x n_mels
-  MelEntry* metaL = (MelEntry*)(melbuf + 16 * p.n_mels);
-  float* melwL = (float*)(metaL + 16 * p.mel_slots);
-  for (int i = tid; i < 16 * p.mel_slots; i += 256) metaL[i] = p.meta[i];
-  for (int i = tid; i < p.mel_wcount; i += 256) melwL[i] = p.melw[i];
-  for (int64_t r0 = (int64_t)blockIdx.x * 16; r0 < rows; r0 += (int64_t)gridDim.x * 16) {
-    const int nr = (int)min((int64_t)16, rows - r0);
+  MelEntry* metaL = (MelEntry*)(smem + ((16 * pitch + 16 * p.n_mels + 3) & ~3));
+  float* melwL = (float*)(metaL + 16 * p.slots);
+  for (int i = tid; i < 16 * p.slots; i += 256) metaL[i] = p.meta[i];
+  for (int i = tid; i < p.wcount; i += 256) melwL[i] = p.melw[i];
+  for (int64_t r0 = (int64_t)blockIdx.x * 16; r0 < p.rows; r0 += (int64_t)gridDim.x * 16) {
+    const int nr = (int)min((int64_t)16, p.rows - r0);
     __syncthreads();
-    for (int i = tid; i < nr * nbins; i += 256) {
-      const int r = i / nbins, k = i - r * nbins;
-      rowsL[r * pitch + k] = spec[(r0 + r) * nbins + k];
+    for (int i = tid; i < nr * p.nbins; i += 256) {
+      const int r = i / p.nbins, k = i - r * p.nbins;
+      rowsL[r * pitch + k] = p.spec[(r0 + r) * p.nbins + k];
     }
     __syncthreads();
     const int r = tid >> 4, l = tid & 15;
-    if (r < nr) mel_project_lane(rowsL + r * pitch, metaL, melwL, p.mel_slots, l, melbuf + r * p.n_mels, p);
+    if (r < nr) {
+      for (int j = 0; j < p.slots; ++j) {
+        const MelEntry e = metaL[l * p.slots + j];
+        if (e.mel < 0) continue;
+        const float* x = rowsL + r * pitch + e.start;
+        const float* w = melwL + e.woff;
+        float acc = 0.0f;
+        for (int i = 0; i < e.len; ++i) acc = __builtin_fmaf(x[i], w[i], acc);
+        float v = log_epilogue(acc, p.log_kind, p.amin, p.db_offset, p.ln_offset);
+        if (p.affine) v = __builtin_fmaf(v, p.aff_scale[e.mel], p.aff_shift[e.mel]);
+        melbuf[r * p.n_mels + e.mel] = v;
+      }
+    }
     __syncthreads();
     for (int i = tid; i < nr * p.n_mels; i += 256) p.out[r0 * p.n_mels + i] = melbuf[i];
   }
@@ -241,13 +320,17 @@ struct sed_plan {
   float* d_window = nullptr;     // 0.5 * window, fp32
   cplx* d_tw1 = nullptr;
   cplx* d_tw2 = nullptr;
-  MelEntry* d_meta = nullptr;    // schedule for the fused kernel (LPF lanes)
-  float* d_melw = nullptr;
-  MelEntry* d_meta16 = nullptr;  // schedule for mel_rows_kernel (16 lanes)
+  // banded mel matrix scheduled for the matrix pipe (fused kernel)
+  float* d_mela = nullptr;
+  int32_t* d_melbase = nullptr;
+  int32_t* d_quadpos = nullptr;
+  int mel_sets = 0, mel_u = 0, mel_maxpos = 0, n_quads = 0;
+  // banded mel matrix scheduled over 16 lanes (mel_rows_kernel)
+  MelEntry* d_meta16 = nullptr;
   float* d_melw16 = nullptr;
+  int mel_slots16 = 0, mel_wcount16 = 0;
   float* d_scale = nullptr;
   float* d_shift = nullptr;
-  int mel_slots = 0, mel_wcount = 0, mel_slots16 = 0, mel_wcount16 = 0;
   bool affine = false;
   float db_offset = 0.0f;
 };
@@ -267,16 +350,18 @@ static int upload(T** dst, const std::vector<T>& src) {
   return SED_OK;
 }
 
-static int lpf_of(int geo) { return geo == 0 ? Geo512::LPF : Geo1024::LPF; }
+static int row_pitch_of(int geo) { return geo == 0 ? Geo512::PP : geo == 1 ? Geo1024::PP : Geo2048::PP; }
 
 static int upload_mel(sed_plan* pl) {
   const int F = pl->cfg.n_fft / 2 + 1, M = pl->cfg.n_mels;
-  MelSchedule s = schedule_mel(pl->melW_host, F, M, lpf_of(pl->geo));
-  pl->mel_slots = s.slots;
-  pl->mel_wcount = (int)s.weights.size();
-  int rc = upload(&pl->d_meta, s.entries);
-  if (rc) return rc;
-  rc = upload(&pl->d_melw, s.weights);
+  const MelMfmaSchedule sc = schedule_mel_mfma(pl->melW_host, F, M, row_pitch_of(pl->geo), kMaxMelSets);
+  pl->mel_sets = sc.sets;
+  pl->mel_u = sc.tau / 4;
+  pl->mel_maxpos = sc.max_pos;
+  pl->n_quads = sc.n_quads;
+  int rc = upload(&pl->d_mela, sc.a);
+  if (!rc) rc = upload(&pl->d_melbase, sc.base);
+  if (!rc) rc = upload(&pl->d_quadpos, sc.quadpos);
   if (rc) return rc;
   MelSchedule s16 = schedule_mel(pl->melW_host, F, M, 16);
   pl->mel_slots16 = s16.slots;
@@ -286,7 +371,7 @@ static int upload_mel(sed_plan* pl) {
   return upload(&pl->d_melw16, s16.weights);
 }
 
-extern "C" const char* sed_version(void) { return "sedhip 0.1.0 (gfx950)"; }
+extern "C" const char* sed_version(void) { return "sedhip 0.2.0 (gfx950)"; }
 
 extern "C" const char* sed_status_string(int status) {
   switch (status) {
@@ -326,7 +411,8 @@ extern "C" int sed_plan_create(const sed_frontend_cfg* cfg, sed_plan** out) {
   else if (cfg->n_fft == 1024) geo = 1;
   else if (cfg->n_fft == 2048) geo = 2;
   else return SED_ERR_UNSUPPORTED_NFFT;
-  if (cfg->win_length < 1 || cfg->win_length > cfg->n_fft || cfg->hop < 4 || cfg->hop % 4 != 0) return SED_ERR_BAD_ARG;
+  if (cfg->win_length < 1 || cfg->win_length > cfg->n_fft) return SED_ERR_BAD_ARG;
+  if (cfg->hop < 4 || cfg->hop % 4 != 0 || cfg->hop > cfg->n_fft) return SED_ERR_BAD_ARG;
   if (cfg->n_mels < 1 || cfg->n_mels > 128 || cfg->sample_rate < 1) return SED_ERR_BAD_ARG;
   if (cfg->spectrum != SED_SPEC_MAGNITUDE && cfg->spectrum != SED_SPEC_POWER) return SED_ERR_BAD_ARG;
   if (cfg->center && cfg->pad_mode != SED_PAD_CONSTANT && cfg->pad_mode != SED_PAD_REFLECT) return SED_ERR_BAD_ARG;
@@ -365,8 +451,8 @@ extern "C" int sed_plan_create(const sed_frontend_cfg* cfg, sed_plan** out) {
 
 extern "C" void sed_plan_destroy(sed_plan* pl) {
   if (!pl) return;
-  void* bufs[] = {pl->d_window, pl->d_tw1, pl->d_tw2, pl->d_meta, pl->d_melw, pl->d_meta16, pl->d_melw16,
-                  pl->d_scale, pl->d_shift};
+  void* bufs[] = {pl->d_window, pl->d_tw1, pl->d_tw2, pl->d_mela, pl->d_melbase, pl->d_quadpos, pl->d_meta16,
+                  pl->d_melw16, pl->d_scale, pl->d_shift};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   delete pl;
@@ -429,8 +515,72 @@ extern "C" int sed_plan_set_affine(sed_plan* pl, const float* scale, const float
   return upload(&pl->d_shift, std::vector<float>(shift, shift + M));
 }
 
-static void fill_common(const sed_plan* pl, FrontParams& p) {
+static inline int round4(int v) { return (v + 3) & ~3; }
+static inline int round64(int v) { return (v + 63) & ~63; }
+
+template <class G, bool MAG, bool SPEC_OUT>
+static int launch_front(const sed_plan* pl, FrontParams p, int64_t B, hipStream_t stream) {
+  // per-wave LDS region
+  p.span = (G::FPW - 1) * p.hop + G::NFFT;
+  p.fresh = G::FPW * p.hop;
+  p.halo = G::NFFT - p.hop;
+  p.reuse_halo = (p.halo > 0 && p.fresh >= p.halo) ? 1 : 0;
+  p.xoff = p.reuse_halo ? round64(p.halo) : 0;
+  const int after_rows = SPEC_OUT ? 0 : p.mel_sets * 256 + G::FPW * p.n_mels;
+  const int xwf = round4(std::max(G::FPW * G::XFR, G::FPW * G::PP + after_rows));
+  p.wave_floats = round64(std::max(p.span, p.xoff + xwf));
+  // shared tables
+  int off = 0;
+  p.off_win = off; off += G::NFFT;
+  p.off_tw1 = off; off += 2 * G::R1 * G::R2;
+  p.off_tw2 = off; off += round4(2 * G::SLOTS * G::LPF);
+  p.off_mela = off; off += SPEC_OUT ? 0 : p.mel_sets * p.mel_u * 256;
+  p.off_melbase = off; off += SPEC_OUT ? 0 : round4(p.mel_sets * 16);
+  p.off_quadpos = off; off += SPEC_OUT ? 0 : round4(p.n_quads * p.mel_maxpos);
+  p.off_wave = round64(off);
+  const size_t lds_bytes = (size_t)(p.off_wave + G::WAVES * p.wave_floats) * sizeof(float);
+  if (lds_bytes > 160 * 1024) return SED_ERR_BAD_ARG;
+  auto kern = stft_mel_kernel<G, MAG, SPEC_OUT>;
+  SED_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds_bytes));
+  // chunks: runs of consecutive frames of one clip, one wavefront each
+  const int per_cu = std::max(1, std::min(2, (int)((160 * 1024) / lds_bytes)));
+  const int64_t max_waves = (int64_t)pl->num_cus * per_cu * G::WAVES;
+  const int64_t total_frames = B * (int64_t)p.T;
+  int64_t cf = (total_frames + max_waves - 1) / max_waves;
+  cf = std::max<int64_t>(cf, 4 * G::FPW);
+  cf = (cf + G::FPW - 1) / G::FPW * G::FPW;
+  cf = std::min<int64_t>(cf, ((int64_t)p.T + G::FPW - 1) / G::FPW * G::FPW);
+  p.chunk_frames = (int32_t)cf;
+  p.chunks_per_clip = (int32_t)((p.T + cf - 1) / cf);
+  const int64_t total_chunks = (int64_t)p.chunks_per_clip * B;
+  if (total_chunks > INT32_MAX / 2) return SED_ERR_BAD_ARG;
+  p.total_chunks = (int32_t)total_chunks;
+  const int blocks = (int)std::min<int64_t>((total_chunks + G::WAVES - 1) / G::WAVES, (int64_t)pl->num_cus * per_cu);
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(G::WAVES * 64), lds_bytes, stream, p);
+  return hip_status(hipGetLastError());
+}
+
+template <bool SPEC_OUT>
+static int front_forward(const sed_plan* pl, const void* pcm, int64_t B, int64_t L, int64_t pcm_stride, float* out,
+                         int64_t out_stride_b, void* stream) {
+  if (!pl || B < 0 || L < 0) return SED_ERR_BAD_ARG;
+  const int64_t T = sed_plan_num_frames(pl, L);
+  if (T < 0) return (int)T;
+  if (B == 0 || T == 0) return SED_OK;
+  if (!pcm || !out || pcm_stride < L) return SED_ERR_BAD_ARG;
+  const int64_t row = SPEC_OUT ? pl->cfg.n_fft / 2 + 1 : pl->cfg.n_mels;
+  if (out_stride_b < T * row || T > INT32_MAX / 4) return SED_ERR_BAD_ARG;
+  int rc = check_device(pl);
+  if (rc) return rc;
   const sed_frontend_cfg& c = pl->cfg;
+  FrontParams p{};
+  p.pcm = pcm;
+  p.out = out;
+  p.L = L;
+  p.pcm_stride = pcm_stride;
+  p.out_stride_b = out_stride_b;
+  p.T = (int32_t)T;
   p.hop = c.hop;
   p.pad_left = c.center ? c.n_fft / 2 : 0;
   p.pad_mode = c.center ? c.pad_mode : SED_PAD_NONE;
@@ -445,73 +595,22 @@ static void fill_common(const sed_plan* pl, FrontParams& p) {
   p.window = pl->d_window;
   p.tw1 = pl->d_tw1;
   p.tw2 = pl->d_tw2;
-  p.meta = pl->d_meta;
-  p.melw = pl->d_melw;
-  p.mel_slots = pl->mel_slots;
-  p.mel_wcount = pl->mel_wcount;
+  p.mela = pl->d_mela;
+  p.melbase = pl->d_melbase;
+  p.quadpos = pl->d_quadpos;
+  p.mel_sets = pl->mel_sets;
+  p.mel_u = pl->mel_u;
+  p.mel_maxpos = pl->mel_maxpos;
+  p.n_quads = pl->n_quads;
   p.aff_scale = pl->d_scale;
   p.aff_shift = pl->d_shift;
-}
-
-static inline int round4(int v) { return (v + 3) & ~3; }
-
-template <class G, bool MAG, bool SPEC_OUT>
-static int launch_front(const sed_plan* pl, FrontParams p, hipStream_t stream) {
-  const int span = round4((G::FPI - 1) * p.hop + G::NFFT);
-  int off = span;
-  p.off_xw = off;
-  p.xwf = round4(std::max(G::FPW * G::XFR, G::FPW * G::PP + (SPEC_OUT ? 0 : G::FPW * p.n_mels)));
-  off += G::WAVES * p.xwf;
-  p.off_win = off; off += G::NFFT;
-  p.off_tw1 = off; off += 2 * G::R1 * G::R2;
-  p.off_tw2 = off; off += round4(2 * G::SLOTS * G::LPF);
-  p.off_meta = off; off += SPEC_OUT ? 0 : 4 * G::LPF * p.mel_slots;
-  p.off_melw = off; off += SPEC_OUT ? 0 : round4(p.mel_wcount);
-  const size_t lds_bytes = (size_t)off * sizeof(float);
-  if (lds_bytes > 160 * 1024) return SED_ERR_BAD_ARG;
-  auto kern = stft_mel_kernel<G, MAG, SPEC_OUT>;
-  SED_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds_bytes));
-  const int per_cu = std::max(1, std::min(8, (int)((160 * 1024) / lds_bytes)));
-  const int grid = std::min(p.total_tiles, pl->num_cus * per_cu);
-  p.tiles_per_block = (p.total_tiles + grid - 1) / grid;
-  const int blocks = (p.total_tiles + p.tiles_per_block - 1) / p.tiles_per_block;
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(G::WAVES * 64), lds_bytes, stream, p);
-  return hip_status(hipGetLastError());
-}
-
-template <bool SPEC_OUT>
-static int front_forward(const sed_plan* pl, const void* pcm, int64_t B, int64_t L, int64_t pcm_stride, float* out,
-                         int64_t out_stride_b, void* stream) {
-  if (!pl || B < 0 || L < 0) return SED_ERR_BAD_ARG;
-  const int64_t T = sed_plan_num_frames(pl, L);
-  if (T < 0) return (int)T;
-  if (B == 0 || T == 0) return SED_OK;
-  if (!pcm || !out || pcm_stride < L) return SED_ERR_BAD_ARG;
-  const int64_t row = SPEC_OUT ? pl->cfg.n_fft / 2 + 1 : pl->cfg.n_mels;
-  if (out_stride_b < T * row) return SED_ERR_BAD_ARG;
-  int rc = check_device(pl);
-  if (rc) return rc;
-  FrontParams p{};
-  fill_common(pl, p);
-  p.pcm = pcm;
-  p.out = out;
-  p.L = L;
-  p.pcm_stride = pcm_stride;
-  p.out_stride_b = out_stride_b;
-  p.T = (int32_t)T;
-  const int fpi = pl->geo == 0 ? Geo512::FPI : pl->geo == 1 ? Geo1024::FPI : Geo2048::FPI;
-  p.tiles_per_clip = (int32_t)((T + fpi - 1) / fpi);
-  const int64_t total = (int64_t)p.tiles_per_clip * B;
-  if (T > INT32_MAX / 2 || total > INT32_MAX / 2) return SED_ERR_BAD_ARG;
-  p.total_tiles = (int32_t)total;
-  const size_t esz = pl->cfg.pcm_kind == SED_PCM_I16 ? 2 : 4;
-  const size_t need = pl->cfg.pcm_kind == SED_PCM_I16 ? 8 : 16;
+  const size_t esz = c.pcm_kind == SED_PCM_I16 ? 2 : 4;
+  const size_t need = c.pcm_kind == SED_PCM_I16 ? 8 : 16;
   p.vec_ok = ((uintptr_t)pcm % need == 0) && ((pcm_stride * esz) % need == 0) ? 1 : 0;
   hipStream_t s = (hipStream_t)stream;
-  const bool mag = pl->cfg.spectrum == SED_SPEC_MAGNITUDE;
-#define SED_DISPATCH(GEO)                                                   \
-  return mag ? launch_front<GEO, true, SPEC_OUT>(pl, p, s) : launch_front<GEO, false, SPEC_OUT>(pl, p, s)
+  const bool mag = c.spectrum == SED_SPEC_MAGNITUDE;
+#define SED_DISPATCH(GEO)                                                         \
+  return mag ? launch_front<GEO, true, SPEC_OUT>(pl, p, B, s) : launch_front<GEO, false, SPEC_OUT>(pl, p, B, s)
   if (pl->geo == 0) { SED_DISPATCH(Geo512); }
   if (pl->geo == 1) { SED_DISPATCH(Geo1024); }
   SED_DISPATCH(Geo2048);
@@ -534,21 +633,31 @@ extern "C" int sed_mel_from_spectrogram(const sed_plan* pl, const float* spec, i
   if (!spec || !out) return SED_ERR_BAD_ARG;
   int rc = check_device(pl);
   if (rc) return rc;
-  FrontParams p{};
-  fill_common(pl, p);
+  const sed_frontend_cfg& c = pl->cfg;
+  MelRowsParams p{};
+  p.spec = spec;
   p.out = out;
+  p.rows = rows;
+  p.nbins = c.n_fft / 2 + 1;
+  p.n_mels = c.n_mels;
+  p.log_kind = c.log_kind;
+  p.affine = pl->affine ? 1 : 0;
+  p.slots = pl->mel_slots16;
+  p.wcount = pl->mel_wcount16;
+  p.amin = c.amin;
+  p.db_offset = pl->db_offset;
+  p.ln_offset = c.ln_offset;
   p.meta = pl->d_meta16;
   p.melw = pl->d_melw16;
-  p.mel_slots = pl->mel_slots16;
-  p.mel_wcount = pl->mel_wcount16;
-  const int nbins = pl->cfg.n_fft / 2 + 1;
-  const size_t lds = sizeof(float) * (16 * (nbins + 3) + 16 * p.n_mels + 4 * 16 * p.mel_slots + p.mel_wcount);
+  p.aff_scale = pl->d_scale;
+  p.aff_shift = pl->d_shift;
+  const size_t lds = sizeof(float) * (((16 * (p.nbins + 3) + 16 * p.n_mels + 3) & ~3) + 4 * 16 * p.slots + p.wcount);
   if (lds > 160 * 1024) return SED_ERR_BAD_ARG;
   SED_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mel_rows_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int64_t groups = (rows + 15) / 16;
   const int grid = (int)std::min<int64_t>(groups, (int64_t)pl->num_cus * 2);
-  hipLaunchKernelGGL(mel_rows_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, p, spec, rows, nbins);
+  hipLaunchKernelGGL(mel_rows_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
   return hip_status(hipGetLastError());
 }
 

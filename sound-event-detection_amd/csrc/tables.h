@@ -156,4 +156,73 @@ inline MelSchedule schedule_mel(const std::vector<float>& melW, int F, int M, in
   return s;
 }
 
+// ---- mel projection on the 4x4x1 16-block f32 MFMA -------------------------------------------------
+// One v_mfma_f32_4x4x1_16b_f32 multiplies, in each of its 16 blocks, 4 filter weights (one bin, 4
+// consecutive mel filters = a "quad") by the powers of that bin in 4 frames.  A "position" is one block
+// of one accumulator set; it owns a segment of at most tau consecutive bins of one quad.  Long quads are
+// cut into several positions so that all positions finish after the same number of instructions.
+struct MelMfmaSchedule {
+  int sets = 0;        // accumulator sets (4 VGPRs each); positions = 16 * sets
+  int tau = 0;         // bins per position, multiple of 4
+  int n_quads = 0;
+  int max_pos = 0;     // most positions any quad was cut into
+  std::vector<float> a;         // [set][tau/4][lane = 4*block + i][4]: weight of bin base+4u+e for mel 4*quad+i
+  std::vector<int32_t> base;    // [set][block]: first bin the position reads (multiple of 4, base + tau <= row_pitch)
+  std::vector<int32_t> quadpos; // [quad][max_pos]: positions (set*16 + block) to add up, -1 padded
+};
+
+inline MelMfmaSchedule schedule_mel_mfma(const std::vector<float>& melW, int F, int M, int row_pitch, int max_sets = 4) {
+  MelMfmaSchedule sc;
+  const int NQ = (M + 3) / 4;
+  sc.n_quads = NQ;
+  std::vector<int> lo(NQ, 0), len(NQ, 0);
+  for (int q = 0; q < NQ; ++q) {
+    int a = F, b = -1;
+    for (int k = 0; k < F; ++k)
+      for (int i = 0; i < 4 && 4 * q + i < M; ++i)
+        if (melW[(size_t)k * M + 4 * q + i] != 0.0f) { a = std::min(a, k); b = std::max(b, k); }
+    if (b >= a) { lo[q] = a / 4 * 4; len[q] = (b + 1 - lo[q] + 3) / 4 * 4; }
+  }
+  auto positions_needed = [&](int tau) {
+    int n = 0;
+    for (int q = 0; q < NQ; ++q) n += std::max(1, (len[q] + tau - 1) / tau);
+    return n;
+  };
+  int best_sets = 0, best_tau = 0;
+  for (int s = 1; s <= max_sets; ++s) {
+    if (16 * s < NQ) continue;
+    int tau = 4;
+    while (positions_needed(tau) > 16 * s) tau += 4;
+    if (best_sets == 0 || s * tau < best_sets * best_tau) { best_sets = s; best_tau = tau; }
+  }
+  sc.sets = best_sets;
+  sc.tau = std::min(best_tau, row_pitch / 4 * 4);
+  const int P = 16 * sc.sets, U = sc.tau / 4;
+  sc.a.assign((size_t)sc.sets * U * 64 * 4, 0.0f);
+  sc.base.assign(P, 0);
+  std::vector<std::vector<int>> of_quad(NQ);
+  int p = 0;
+  for (int q = 0; q < NQ; ++q) {
+    const int nseg = std::max(1, (len[q] + sc.tau - 1) / sc.tau);
+    for (int g = 0; g < nseg; ++g, ++p) {
+      const int seg_lo = lo[q] + g * sc.tau, seg_hi = std::min(lo[q] + len[q], seg_lo + sc.tau);  // bins owned
+      const int base = std::max(0, std::min(seg_lo, row_pitch - sc.tau));                          // bins read
+      sc.base[p] = base;
+      of_quad[q].push_back(p);
+      const int set = p / 16, block = p % 16;
+      for (int t = 0; t < sc.tau; ++t) {
+        const int k = base + t;
+        if (k < seg_lo || k >= seg_hi || k >= F) continue;
+        for (int i = 0; i < 4 && 4 * q + i < M; ++i)
+          sc.a[(((size_t)set * U + t / 4) * 64 + 4 * block + i) * 4 + t % 4] = melW[(size_t)k * M + 4 * q + i];
+      }
+    }
+  }
+  for (const auto& v : of_quad) sc.max_pos = std::max(sc.max_pos, (int)v.size());
+  sc.quadpos.assign((size_t)NQ * sc.max_pos, -1);
+  for (int q = 0; q < NQ; ++q)
+    for (size_t i = 0; i < of_quad[q].size(); ++i) sc.quadpos[(size_t)q * sc.max_pos + i] = of_quad[q][i];
+  return sc;
+}
+
 }  // namespace sed
