@@ -72,10 +72,8 @@ static double check_mel_schedule(int sr, int n_fft, int M, double fmin, double f
   for (int j = 0; j < 4; ++j)
     for (int m = 0; m < M; ++m) {
       double got = 0.0, want = 0.0;
-      for (int pi = 0; pi < sc.max_pos; ++pi) {
-        const int pos = sc.quadpos[(size_t)(m / 4) * sc.max_pos + pi];
-        if (pos >= 0) got += part[((size_t)pos * 4 + m % 4) * 4 + j];
-      }
+      const int first = sc.quadpos[m / 4] & 0xffff, npos = sc.quadpos[m / 4] >> 16;
+      for (int pi = 0; pi < npos; ++pi) got += part[((size_t)(first + pi) * 4 + m % 4) * 4 + j];
       for (int k = 0; k < F; ++k) want += (double)W[(size_t)k * M + m] * pw[j * pitch + k];
       worst = std::max(worst, std::fabs(got - want) / std::max(1e-30, std::fabs(want)));
     }

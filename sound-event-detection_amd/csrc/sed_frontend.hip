@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -26,6 +27,14 @@ using Geo1024 = Geo<32, 16, 16, 8>;
 using Geo2048 = Geo<32, 32, 16, 4>;
 
 constexpr int kMaxMelSets = 4;
+
+// Timing ablations: build with -DSED_ABLATION and set SED_DEBUG_SKIP=<mask> to leave phases of the streaming loop
+// out (results are then garbage).  In normal builds the tests below fold to false.
+#ifdef SED_ABLATION
+#define SED_SKIP(p, bit) (((p).skip & (bit)) != 0)
+#else
+#define SED_SKIP(p, bit) false
+#endif
 typedef float f4v __attribute__((ext_vector_type(4)));
 
 struct FrontParams {
@@ -35,7 +44,7 @@ struct FrontParams {
   int32_t T, hop, pad_left, pad_mode, pcm_kind, vec_ok;
   float pcm_div;
   int32_t n_mels, log_kind, affine;
-  float amin, db_offset, ln_offset;
+  float amin, db_offset, ln_offset, inv_n_mels;
   int32_t chunk_frames, chunks_per_clip, total_chunks;
   // per-wave LDS region, in floats: [0, span) PCM span of FPW frames; X = region + xoff holds, in turn, the
   // exchange rows, then [power rows | mel partial sums | mel rows]
@@ -43,6 +52,7 @@ struct FrontParams {
   // LDS carve of the shared tables, in floats
   int32_t off_win, off_tw1, off_tw2, off_mela, off_melbase, off_quadpos, off_wave;
   int32_t mel_sets, mel_u, mel_maxpos, n_quads;
+  int32_t skip;  // diagnostic: bit k set = phase k of the streaming loop is not executed (timing ablations only)
   const float* window;
   const cplx* tw1;
   const cplx* tw2;
@@ -61,9 +71,11 @@ __device__ __forceinline__ void wave_phase_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// log2 on the transcendental unit (v_log_f32, about 1 ulp of the log2 value), scaled to dB or nepers: the
+// arguments are clamped or offset away from zero, so no denormal handling is needed.
 __device__ __forceinline__ float log_epilogue(float acc, int log_kind, float amin, float db_offset, float ln_offset) {
-  if (log_kind == SED_LOG_DB10) return 10.0f * log10f(fmaxf(acc, amin)) - db_offset;
-  if (log_kind == SED_LOG_LN) return logf(acc + ln_offset);
+  if (log_kind == SED_LOG_DB10) return 3.0102999566398120f * __log2f(fmaxf(acc, amin)) - db_offset;
+  if (log_kind == SED_LOG_LN) return 0.6931471805599453f * __log2f(acc + ln_offset);
   return acc;
 }
 
@@ -92,17 +104,37 @@ __device__ __attribute__((noinline)) void stage_span_edges(const void* pcm, int 
 }
 
 // One wavefront copies `count` samples (multiple of 4) of clip b, starting at padded-clip sample s0, to LDS.
+// The fast path issues its loads in batches of 8 x 16 B per lane before the first LDS store, with clamped
+// (never predicated) addresses: a load under a divergent branch would be waited for on its own.
 __device__ __forceinline__ void stage_span(const FrontParams& p, float* dst, int64_t b, int64_t s0, int count, int lane) {
   const bool fast = s0 >= 0 && s0 + count <= p.L && p.vec_ok;
   if (fast && p.pcm_kind == SED_PCM_F32) {
     const float* src = (const float*)p.pcm + b * p.pcm_stride + s0;
-    for (int i = 4 * lane; i < count; i += 256) *(float4*)(dst + i) = *(const float4*)(src + i);
+    for (int base = 0; base < count; base += 8 * 256) {
+      float4 v[8];
+      static_for<0, 8>([&](auto Kf) {
+        const int i = min(base + 256 * decltype(Kf)::value + 4 * lane, count - 4);
+        v[decltype(Kf)::value] = *(const float4*)(src + i);
+      });
+      static_for<0, 8>([&](auto Kf) {
+        const int i = min(base + 256 * decltype(Kf)::value + 4 * lane, count - 4);
+        *(float4*)(dst + i) = v[decltype(Kf)::value];
+      });
+    }
   } else if (fast) {
     const int16_t* src = (const int16_t*)p.pcm + b * p.pcm_stride + s0;
-    for (int i = 4 * lane; i < count; i += 256) {
-      const short4 v = *(const short4*)(src + i);
-      *(float4*)(dst + i) = make_float4((float)v.x / p.pcm_div, (float)v.y / p.pcm_div, (float)v.z / p.pcm_div,
-                                        (float)v.w / p.pcm_div);
+    for (int base = 0; base < count; base += 8 * 256) {
+      short4 v[8];
+      static_for<0, 8>([&](auto Kf) {
+        const int i = min(base + 256 * decltype(Kf)::value + 4 * lane, count - 4);
+        v[decltype(Kf)::value] = *(const short4*)(src + i);
+      });
+      static_for<0, 8>([&](auto Kf) {
+        const int i = min(base + 256 * decltype(Kf)::value + 4 * lane, count - 4);
+        const short4 w = v[decltype(Kf)::value];
+        *(float4*)(dst + i) = make_float4((float)w.x / p.pcm_div, (float)w.y / p.pcm_div, (float)w.z / p.pcm_div,
+                                          (float)w.w / p.pcm_div);
+      });
     }
   } else {
     stage_span_edges(p.pcm, p.pcm_kind, p.pcm_div, p.L, p.pad_mode, b * p.pcm_stride, dst, s0, count, lane);
@@ -112,30 +144,63 @@ __device__ __forceinline__ void stage_span(const FrontParams& p, float* dst, int
 // Mel projection of 4 frames (power rows prow0 + j*PITCH, j = 0..3) on the matrix pipe, then log/affine.
 // Lane 4*block + j feeds the power of frame j as the B operand and the weight of filter 4*quad + j as the
 // A operand of block `block`; after the last instruction it holds, in acc[set][i], the partial sum of filter
-// 4*quad + i for frame j over the bins of position (set, block).
+// 4*quad + i for frame j over the bins of position (set, block).  Operands of step u+1 are fetched from LDS
+// before the instructions of step u are issued, and the accumulator sets advance together.
 template <int PITCH>
 __device__ __forceinline__ void mel_mfma_4frames(const FrontParams& p, const float* prow0, const float* mela,
                                                  const int32_t* melbase, const int32_t* quadpos, float* part,
                                                  float* melrows, int lane) {
+  // Everything below depends only on the lane and on launch constants; hiding the lane id from the optimiser keeps
+  // those addresses from being computed once and held in registers across the FFT phases of the streaming loop.
+  asm volatile("" : "+v"(lane));
   const int blk = lane >> 2, j = lane & 3;
   const float* prow = prow0 + j * PITCH;
   f4v acc[kMaxMelSets];
+  const float* ap[kMaxMelSets];
+  const float* bp[kMaxMelSets];
+  f4 a[kMaxMelSets], b[kMaxMelSets];
   static_for<0, kMaxMelSets>([&](auto Sf) {
     constexpr int s = decltype(Sf)::value;
     acc[s] = f4v{0.0f, 0.0f, 0.0f, 0.0f};
     if (s < p.mel_sets) {
-      const float* bp = prow + melbase[s * 16 + blk];
-      const float* ap = mela + ((size_t)s * p.mel_u * 64 + lane) * 4;
-      for (int u = 0; u < p.mel_u; ++u) {
-        const f4 a = ld4(ap + u * 256);
-        const f4 b = ld4(bp + 4 * u);
-        acc[s] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.x, b.x, acc[s], 0, 0, 0);
-        acc[s] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.y, b.y, acc[s], 0, 0, 0);
-        acc[s] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.z, b.z, acc[s], 0, 0, 0);
-        acc[s] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.w, b.w, acc[s], 0, 0, 0);
-      }
+      bp[s] = prow + melbase[s * 16 + blk];
+      ap[s] = mela + ((size_t)s * p.mel_u * 64 + lane) * 4;
+      a[s] = ld4(ap[s]);
+      b[s] = ld4(bp[s]);
     }
   });
+  const int n_u = SED_SKIP(p, 32) ? 0 : p.mel_u;
+  for (int u = 0; u < n_u; ++u) {
+    f4 an[kMaxMelSets], bn[kMaxMelSets];
+    const int un = min(u + 1, p.mel_u - 1);
+    static_for<0, kMaxMelSets>([&](auto Sf) {
+      constexpr int s = decltype(Sf)::value;
+      if (s < p.mel_sets) {
+        an[s] = ld4(ap[s] + un * 256);
+        bn[s] = ld4(bp[s] + 4 * un);
+      }
+    });
+    static_for<0, kMaxMelSets>([&](auto Sf) {
+      constexpr int s = decltype(Sf)::value;
+      if (s < p.mel_sets) acc[s] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[s].x, b[s].x, acc[s], 0, 0, 0);
+    });
+    static_for<0, kMaxMelSets>([&](auto Sf) {
+      constexpr int s = decltype(Sf)::value;
+      if (s < p.mel_sets) acc[s] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[s].y, b[s].y, acc[s], 0, 0, 0);
+    });
+    static_for<0, kMaxMelSets>([&](auto Sf) {
+      constexpr int s = decltype(Sf)::value;
+      if (s < p.mel_sets) acc[s] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[s].z, b[s].z, acc[s], 0, 0, 0);
+    });
+    static_for<0, kMaxMelSets>([&](auto Sf) {
+      constexpr int s = decltype(Sf)::value;
+      if (s < p.mel_sets) {
+        acc[s] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[s].w, b[s].w, acc[s], 0, 0, 0);
+        a[s] = an[s];
+        b[s] = bn[s];
+      }
+    });
+  }
   static_for<0, kMaxMelSets>([&](auto Sf) {
     constexpr int s = decltype(Sf)::value;
     if (s < p.mel_sets) {
@@ -144,19 +209,28 @@ __device__ __forceinline__ void mel_mfma_4frames(const FrontParams& p, const flo
     }
   });
   wave_phase_fence();
-  const int n_out = 4 * p.n_mels;
-  for (int o = lane; o < n_out; o += 64) {
-    const int jj = o / p.n_mels, m = o - jj * p.n_mels;
-    const int32_t* qp = quadpos + (m >> 2) * p.mel_maxpos;
-    float acc1 = 0.0f;
-    for (int i = 0; i < p.mel_maxpos; ++i) {
-      const int pos = qp[i];
-      if (pos >= 0) acc1 += part[pos * 16 + (m & 3) * 4 + jj];
+  // output o = 64*r + lane is (frame o / n_mels, filter o % n_mels); its partial sums sit 16 floats apart
+  const int n_out = SED_SKIP(p, 64) ? 0 : 4 * p.n_mels;
+  static_for<0, 8>([&](auto Rf) {
+    constexpr int r = decltype(Rf)::value;
+    if (64 * r < n_out) {
+      const int o = 64 * r + lane;
+      const int jj = (int)(((float)o + 0.5f) * p.inv_n_mels);
+      const int m = o - jj * p.n_mels;
+      const int info = quadpos[min(m, p.n_mels - 1) >> 2];
+      const int npos = info >> 16;
+      const float* pp = part + (info & 0xffff) * 16 + (m & 3) * 4 + min(jj, 3);
+      float sum = 0.0f;
+      for (int i0 = 0; i0 < npos; i0 += 8) {
+        float v[8];
+        static_for<0, 8>([&](auto If) { v[decltype(If)::value] = pp[(i0 + decltype(If)::value) * 16]; });
+        static_for<0, 8>([&](auto If) { sum += (i0 + decltype(If)::value < npos) ? v[decltype(If)::value] : 0.0f; });
+      }
+      float val = log_epilogue(sum, p.log_kind, p.amin, p.db_offset, p.ln_offset);
+      if (p.affine) val = __builtin_fmaf(val, p.aff_scale[min(m, p.n_mels - 1)], p.aff_shift[min(m, p.n_mels - 1)]);
+      if (o < n_out) melrows[o] = val;
     }
-    float v = log_epilogue(acc1, p.log_kind, p.amin, p.db_offset, p.ln_offset);
-    if (p.affine) v = __builtin_fmaf(v, p.aff_scale[m], p.aff_shift[m]);
-    melrows[jj * p.n_mels + m] = v;
-  }
+  });
   wave_phase_fence();
 }
 
@@ -165,7 +239,8 @@ __global__ void __launch_bounds__(G::WAVES * 64, G::WAVES == 8 ? 2 : 1) stft_mel
   extern __shared__ __align__(16) float smem[];
   constexpr int NT = G::WAVES * 64;
   const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: chunk bookkeeping stays scalar
+  const int lane = tid & 63;
   const int fi = lane / G::LPF, l = lane % G::LPF;
 
   float* winL = smem + p.off_win;
@@ -183,7 +258,7 @@ __global__ void __launch_bounds__(G::WAVES * 64, G::WAVES == 8 ? 2 : 1) stft_mel
   if constexpr (!SPEC_OUT) {
     for (int i = tid; i < p.mel_sets * p.mel_u * 256; i += NT) melaL[i] = p.mela[i];
     for (int i = tid; i < p.mel_sets * 16; i += NT) melbaseL[i] = p.melbase[i];
-    for (int i = tid; i < p.n_quads * p.mel_maxpos; i += NT) quadposL[i] = p.quadpos[i];
+    for (int i = tid; i < p.n_quads; i += NT) quadposL[i] = p.quadpos[i];
   }
   __syncthreads();
 
@@ -194,27 +269,33 @@ __global__ void __launch_bounds__(G::WAVES * 64, G::WAVES == 8 ? 2 : 1) stft_mel
     const int f_end = min(p.T, f_begin + p.chunk_frames);
     for (int f0 = f_begin; f0 < f_end; f0 += G::FPW) {
       const int64_t s0 = (int64_t)f0 * p.hop - p.pad_left;
-      if (f0 == f_begin || !p.reuse_halo) stage_span(p, S, b, s0, p.span, lane);
-      else stage_span(p, S + p.halo, b, s0 + p.halo, p.fresh, lane);
+      if (SED_SKIP(p, 1)) {
+      } else if (f0 == f_begin || !p.reuse_halo) {
+        stage_span(p, S, b, s0, p.span, lane);
+      } else {
+        stage_span(p, S + p.halo, b, s0 + p.halo, p.fresh, lane);
+      }
       wave_phase_fence();
       LaneState<G> st;
-      lane_stage1<G>(st, S + fi * p.hop, winL, tw1L, l);
+      if (!SED_SKIP(p, 2)) lane_stage1<G>(st, S + fi * p.hop, winL, tw1L, l);
       wave_phase_fence();
-      if (p.reuse_halo)  // the samples shared with the next FPW frames move to the front of the region
+      if (p.reuse_halo && !SED_SKIP(p, 4))  // the samples shared with the next FPW frames move to the front of the region
         for (int i = 4 * lane; i < p.halo; i += 256) st4(S + i, ld4(S + p.fresh + i));
       float* xfr = X + fi * G::XFR;
-      lane_xwrite<G, 0>(st, xfr, l);
-      wave_phase_fence();
-      lane_xread<G, 0>(st, xfr, l);
-      wave_phase_fence();
-      lane_xwrite<G, 1>(st, xfr, l);
-      wave_phase_fence();
-      lane_xread<G, 1>(st, xfr, l);
-      wave_phase_fence();
+      if (!SED_SKIP(p, 8)) {
+        lane_xwrite<G, 0>(st, xfr, l);
+        wave_phase_fence();
+        lane_xread<G, 0>(st, xfr, l);
+        wave_phase_fence();
+        lane_xwrite<G, 1>(st, xfr, l);
+        wave_phase_fence();
+        lane_xread<G, 1>(st, xfr, l);
+        wave_phase_fence();
+      }
       float* pw = X + fi * G::PP;
       int slot_stride = lane_slot_stride<G>(l);
       asm volatile("" : "+v"(slot_stride));  // opaque: per-slot addresses are formed here, not kept in registers
-      lane_stage2_power<G, MAG>(st, pw, tw2L, l, slot_stride);
+      if (!SED_SKIP(p, 16)) lane_stage2_power<G, MAG>(st, pw, tw2L, l, slot_stride);
       if (l == 0) { pw[G::NBINS] = 0.0f; pw[G::NBINS + 1] = 0.0f; pw[G::NBINS + 2] = 0.0f; }
       wave_phase_fence();
       const int nvalid = min(G::FPW, f_end - f0);
@@ -228,7 +309,7 @@ __global__ void __launch_bounds__(G::WAVES * 64, G::WAVES == 8 ? 2 : 1) stft_mel
         for (int g = 0; g < G::FPW / 4; ++g)
           mel_mfma_4frames<G::PP>(p, X + 4 * g * G::PP, melaL, melbaseL, quadposL, part, melrows + 4 * g * p.n_mels, lane);
         float* dst = p.out + (int64_t)b * p.out_stride_b + (int64_t)f0 * p.n_mels;
-        const int n = nvalid * p.n_mels;
+        const int n = SED_SKIP(p, 128) ? 0 : nvalid * p.n_mels;
         for (int i = lane; i < n; i += 64) dst[i] = melrows[i];
       }
       wave_phase_fence();
@@ -536,7 +617,7 @@ static int launch_front(const sed_plan* pl, FrontParams p, int64_t B, hipStream_
   p.off_tw2 = off; off += round4(2 * G::SLOTS * G::LPF);
   p.off_mela = off; off += SPEC_OUT ? 0 : p.mel_sets * p.mel_u * 256;
   p.off_melbase = off; off += SPEC_OUT ? 0 : round4(p.mel_sets * 16);
-  p.off_quadpos = off; off += SPEC_OUT ? 0 : round4(p.n_quads * p.mel_maxpos);
+  p.off_quadpos = off; off += SPEC_OUT ? 0 : round4(p.n_quads);
   p.off_wave = round64(off);
   const size_t lds_bytes = (size_t)(p.off_wave + G::WAVES * p.wave_floats) * sizeof(float);
   if (lds_bytes > 160 * 1024) return SED_ERR_BAD_ARG;
@@ -550,6 +631,8 @@ static int launch_front(const sed_plan* pl, FrontParams p, int64_t B, hipStream_
   int64_t cf = (total_frames + max_waves - 1) / max_waves;
   cf = std::max<int64_t>(cf, 4 * G::FPW);
   cf = (cf + G::FPW - 1) / G::FPW * G::FPW;
+  static const int debug_chunk = getenv("SED_DEBUG_CHUNK") ? atoi(getenv("SED_DEBUG_CHUNK")) : 0;
+  if (debug_chunk > 0) cf = debug_chunk;
   cf = std::min<int64_t>(cf, ((int64_t)p.T + G::FPW - 1) / G::FPW * G::FPW);
   p.chunk_frames = (int32_t)cf;
   p.chunks_per_clip = (int32_t)((p.T + cf - 1) / cf);
@@ -587,6 +670,7 @@ static int front_forward(const sed_plan* pl, const void* pcm, int64_t B, int64_t
   p.pcm_kind = c.pcm_kind;
   p.pcm_div = c.pcm_kind == SED_PCM_I16 ? c.pcm_divisor : 1.0f;
   p.n_mels = c.n_mels;
+  p.inv_n_mels = 1.0f / (float)c.n_mels;
   p.log_kind = c.log_kind;
   p.affine = pl->affine ? 1 : 0;
   p.amin = c.amin;
@@ -607,6 +691,8 @@ static int front_forward(const sed_plan* pl, const void* pcm, int64_t B, int64_t
   const size_t esz = c.pcm_kind == SED_PCM_I16 ? 2 : 4;
   const size_t need = c.pcm_kind == SED_PCM_I16 ? 8 : 16;
   p.vec_ok = ((uintptr_t)pcm % need == 0) && ((pcm_stride * esz) % need == 0) ? 1 : 0;
+  static const int debug_skip = getenv("SED_DEBUG_SKIP") ? atoi(getenv("SED_DEBUG_SKIP")) : 0;
+  p.skip = debug_skip;
   hipStream_t s = (hipStream_t)stream;
   const bool mag = c.spectrum == SED_SPEC_MAGNITUDE;
 #define SED_DISPATCH(GEO)                                                         \

@@ -168,7 +168,7 @@ struct MelMfmaSchedule {
   int max_pos = 0;     // most positions any quad was cut into
   std::vector<float> a;         // [set][tau/4][lane = 4*block + i][4]: weight of bin base+4u+e for mel 4*quad+i
   std::vector<int32_t> base;    // [set][block]: first bin the position reads (multiple of 4, base + tau <= row_pitch)
-  std::vector<int32_t> quadpos; // [quad][max_pos]: positions (set*16 + block) to add up, -1 padded
+  std::vector<int32_t> quadpos; // [quad]: first position | (number of positions << 16); a quad's positions are consecutive
 };
 
 inline MelMfmaSchedule schedule_mel_mfma(const std::vector<float>& melW, int F, int M, int row_pitch, int max_sets = 4) {
@@ -219,9 +219,8 @@ inline MelMfmaSchedule schedule_mel_mfma(const std::vector<float>& melW, int F, 
     }
   }
   for (const auto& v : of_quad) sc.max_pos = std::max(sc.max_pos, (int)v.size());
-  sc.quadpos.assign((size_t)NQ * sc.max_pos, -1);
-  for (int q = 0; q < NQ; ++q)
-    for (size_t i = 0; i < of_quad[q].size(); ++i) sc.quadpos[(size_t)q * sc.max_pos + i] = of_quad[q][i];
+  sc.quadpos.assign(NQ, 0);
+  for (int q = 0; q < NQ; ++q) sc.quadpos[q] = of_quad[q].front() | ((int32_t)of_quad[q].size() << 16);
   return sc;
 }
 
