@@ -36,6 +36,9 @@ constexpr int kMaxMelSets = 4;
 #define SED_SKIP(p, bit) false
 #endif
 typedef float f4v __attribute__((ext_vector_type(4)));
+struct alignas(8) i16x4 {
+  int16_t x, y, z, w;
+};
 
 struct FrontParams {
   const void* pcm;
@@ -50,8 +53,9 @@ struct FrontParams {
   // exchange rows, then [power rows | mel partial sums | mel rows]
   int32_t span, halo, fresh, reuse_halo, xoff, wave_floats;
   // LDS carve of the shared tables, in floats
-  int32_t off_win, off_tw1, off_tw2, off_mela, off_melbase, off_quadpos, off_wave;
+  int32_t off_win, off_tw1, off_tw2, off_mela, off_melbase, off_quadpos, off_boff, off_gw, off_wave;
   int32_t mel_sets, mel_u, mel_maxpos, n_quads;
+  unsigned long long* stamps;  // diagnostic build only: [wave][8] cycle sums
   int32_t skip;  // diagnostic: bit k set = phase k of the streaming loop is not executed (timing ablations only)
   const float* window;
   const cplx* tw1;
@@ -62,6 +66,22 @@ struct FrontParams {
   const float* aff_scale;
   const float* aff_shift;
 };
+
+// In-kernel phase timing (diagnostic build, -DSED_STAMPS): cycles per phase summed per wavefront.
+#ifdef SED_STAMPS
+#define SED_STAMP_DECL unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_t = sed_stamp();
+#define SED_STAMP(k) { const unsigned long long t_ = sed_stamp(); st_acc[k] += t_ - st_t; st_t = t_; }
+__device__ __forceinline__ unsigned long long sed_stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#else
+#define SED_STAMP_DECL
+#define SED_STAMP(k)
+#endif
 
 // Orders LDS accesses of different lanes of ONE wavefront (the hardware executes a wave's LDS operations in
 // order; this only stops the compiler from moving them across the phase boundary).
@@ -111,29 +131,26 @@ __device__ __forceinline__ void stage_span(const FrontParams& p, float* dst, int
   if (fast && p.pcm_kind == SED_PCM_F32) {
     const float* src = (const float*)p.pcm + b * p.pcm_stride + s0;
     for (int base = 0; base < count; base += 8 * 256) {
-      float4 v[8];
+      f4 v[8];
       static_for<0, 8>([&](auto Kf) {
-        const int i = min(base + 256 * decltype(Kf)::value + 4 * lane, count - 4);
-        v[decltype(Kf)::value] = *(const float4*)(src + i);
+        v[decltype(Kf)::value] = ld4(src + min(base + 256 * decltype(Kf)::value + 4 * lane, count - 4));
       });
       static_for<0, 8>([&](auto Kf) {
-        const int i = min(base + 256 * decltype(Kf)::value + 4 * lane, count - 4);
-        *(float4*)(dst + i) = v[decltype(Kf)::value];
+        st4(dst + min(base + 256 * decltype(Kf)::value + 4 * lane, count - 4), v[decltype(Kf)::value]);
       });
     }
   } else if (fast) {
     const int16_t* src = (const int16_t*)p.pcm + b * p.pcm_stride + s0;
     for (int base = 0; base < count; base += 8 * 256) {
-      short4 v[8];
+      i16x4 v[8];
       static_for<0, 8>([&](auto Kf) {
-        const int i = min(base + 256 * decltype(Kf)::value + 4 * lane, count - 4);
-        v[decltype(Kf)::value] = *(const short4*)(src + i);
+        v[decltype(Kf)::value] =
+            *reinterpret_cast<const i16x4*>(src + min(base + 256 * decltype(Kf)::value + 4 * lane, count - 4));
       });
       static_for<0, 8>([&](auto Kf) {
-        const int i = min(base + 256 * decltype(Kf)::value + 4 * lane, count - 4);
-        const short4 w = v[decltype(Kf)::value];
-        *(float4*)(dst + i) = make_float4((float)w.x / p.pcm_div, (float)w.y / p.pcm_div, (float)w.z / p.pcm_div,
-                                          (float)w.w / p.pcm_div);
+        const i16x4 w = v[decltype(Kf)::value];
+        st4(dst + min(base + 256 * decltype(Kf)::value + 4 * lane, count - 4),
+            f4{(float)w.x / p.pcm_div, (float)w.y / p.pcm_div, (float)w.z / p.pcm_div, (float)w.w / p.pcm_div});
       });
     }
   } else {
@@ -141,66 +158,62 @@ __device__ __forceinline__ void stage_span(const FrontParams& p, float* dst, int
   }
 }
 
-// Mel projection of 4 frames (power rows prow0 + j*PITCH, j = 0..3) on the matrix pipe, then log/affine.
+// Per-lane constants of the mel stage, computed once per kernel launch and kept in registers.
+// gather word of output 64*r + lane: bits 0-10 offset of its first partial sum, 11-15 number of partial sums,
+// 16-22 filter index, 23-24 frame (0..3).
+__device__ __forceinline__ int mel_gather_word(const FrontParams& p, const int32_t* quadpos, int o) {
+  o = min(o, 4 * p.n_mels - 1);
+  const int jj = o / p.n_mels, m = o - jj * p.n_mels;
+  const int info = quadpos[m >> 2];
+  return ((info & 0xffff) * 16 + (m & 3) * 4 + jj) | ((info >> 16) << 11) | (m << 16) | (jj << 23);
+}
+
+// Mel projection of 4 frames (power rows prow0 + j*PITCH, j = 0..3) on the matrix pipe, then log/affine, then the
+// store of the (up to 4) x n_mels outputs straight to global memory.
 // Lane 4*block + j feeds the power of frame j as the B operand and the weight of filter 4*quad + j as the
 // A operand of block `block`; after the last instruction it holds, in acc[set][i], the partial sum of filter
-// 4*quad + i for frame j over the bins of position (set, block).  Operands of step u+1 are fetched from LDS
-// before the instructions of step u are issued, and the accumulator sets advance together.
-template <int PITCH>
-__device__ __forceinline__ void mel_mfma_4frames(const FrontParams& p, const float* prow0, const float* mela,
-                                                 const int32_t* melbase, const int32_t* quadpos, float* part,
-                                                 float* melrows, int lane) {
-  // Everything below depends only on the lane and on launch constants; hiding the lane id from the optimiser keeps
-  // those addresses from being computed once and held in registers across the FFT phases of the streaming loop.
-  asm volatile("" : "+v"(lane));
+// 4*quad + i for frame j over the bins of position (set, block).  Each set's operands are fetched with one
+// burst of LDS reads; the partial sums of a filter are combined through LDS (they sit 16 floats apart).
+template <int UMAX>
+__device__ __forceinline__ void mel_mfma_4frames(const FrontParams& p, const int32_t* boffL, const int32_t* gwL,
+                                                 const float* prow0, const float* mela, float* part, float* dst,
+                                                 int nvalid, int lane) {
+  // per-lane constants come from LDS tables ([set][lane], [r][lane]) in the same burst as the first operands
+  asm volatile("" : "+v"(lane));  // keeps the table reads inside the streaming loop instead of pinning registers
   const int blk = lane >> 2, j = lane & 3;
-  const float* prow = prow0 + j * PITCH;
+  int boff[kMaxMelSets], gw[8];
+  static_for<0, kMaxMelSets>([&](auto Sf) { boff[decltype(Sf)::value] = boffL[decltype(Sf)::value * 64 + lane]; });
+  static_for<0, 8>([&](auto Rf) {
+    constexpr int r = decltype(Rf)::value;
+    gw[r] = (64 * r < 4 * p.n_mels) ? gwL[r * 64 + lane] : 0;
+  });
   f4v acc[kMaxMelSets];
-  const float* ap[kMaxMelSets];
-  const float* bp[kMaxMelSets];
-  f4 a[kMaxMelSets], b[kMaxMelSets];
   static_for<0, kMaxMelSets>([&](auto Sf) {
     constexpr int s = decltype(Sf)::value;
     acc[s] = f4v{0.0f, 0.0f, 0.0f, 0.0f};
     if (s < p.mel_sets) {
-      bp[s] = prow + melbase[s * 16 + blk];
-      ap[s] = mela + ((size_t)s * p.mel_u * 64 + lane) * 4;
-      a[s] = ld4(ap[s]);
-      b[s] = ld4(bp[s]);
+      const float* bp = prow0 + boff[s];
+      const float* ap = mela + ((size_t)s * p.mel_u * 64 + lane) * 4;
+      for (int u0 = 0; u0 < p.mel_u; u0 += UMAX) {
+        f4 a[UMAX], b[UMAX];
+        static_for<0, UMAX>([&](auto Uf) {
+          constexpr int k = decltype(Uf)::value;
+          const int u = min(u0 + k, p.mel_u - 1);
+          a[k] = ld4(ap + u * 256);
+          b[k] = ld4(bp + 4 * u);
+        });
+        static_for<0, UMAX>([&](auto Uf) {
+          constexpr int k = decltype(Uf)::value;
+          if (u0 + k < p.mel_u) {
+            acc[s] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[k].x, b[k].x, acc[s], 0, 0, 0);
+            acc[s] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[k].y, b[k].y, acc[s], 0, 0, 0);
+            acc[s] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[k].z, b[k].z, acc[s], 0, 0, 0);
+            acc[s] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[k].w, b[k].w, acc[s], 0, 0, 0);
+          }
+        });
+      }
     }
   });
-  const int n_u = SED_SKIP(p, 32) ? 0 : p.mel_u;
-  for (int u = 0; u < n_u; ++u) {
-    f4 an[kMaxMelSets], bn[kMaxMelSets];
-    const int un = min(u + 1, p.mel_u - 1);
-    static_for<0, kMaxMelSets>([&](auto Sf) {
-      constexpr int s = decltype(Sf)::value;
-      if (s < p.mel_sets) {
-        an[s] = ld4(ap[s] + un * 256);
-        bn[s] = ld4(bp[s] + 4 * un);
-      }
-    });
-    static_for<0, kMaxMelSets>([&](auto Sf) {
-      constexpr int s = decltype(Sf)::value;
-      if (s < p.mel_sets) acc[s] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[s].x, b[s].x, acc[s], 0, 0, 0);
-    });
-    static_for<0, kMaxMelSets>([&](auto Sf) {
-      constexpr int s = decltype(Sf)::value;
-      if (s < p.mel_sets) acc[s] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[s].y, b[s].y, acc[s], 0, 0, 0);
-    });
-    static_for<0, kMaxMelSets>([&](auto Sf) {
-      constexpr int s = decltype(Sf)::value;
-      if (s < p.mel_sets) acc[s] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[s].z, b[s].z, acc[s], 0, 0, 0);
-    });
-    static_for<0, kMaxMelSets>([&](auto Sf) {
-      constexpr int s = decltype(Sf)::value;
-      if (s < p.mel_sets) {
-        acc[s] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[s].w, b[s].w, acc[s], 0, 0, 0);
-        a[s] = an[s];
-        b[s] = bn[s];
-      }
-    });
-  }
   static_for<0, kMaxMelSets>([&](auto Sf) {
     constexpr int s = decltype(Sf)::value;
     if (s < p.mel_sets) {
@@ -209,17 +222,12 @@ __device__ __forceinline__ void mel_mfma_4frames(const FrontParams& p, const flo
     }
   });
   wave_phase_fence();
-  // output o = 64*r + lane is (frame o / n_mels, filter o % n_mels); its partial sums sit 16 floats apart
   const int n_out = SED_SKIP(p, 64) ? 0 : 4 * p.n_mels;
   static_for<0, 8>([&](auto Rf) {
     constexpr int r = decltype(Rf)::value;
     if (64 * r < n_out) {
-      const int o = 64 * r + lane;
-      const int jj = (int)(((float)o + 0.5f) * p.inv_n_mels);
-      const int m = o - jj * p.n_mels;
-      const int info = quadpos[min(m, p.n_mels - 1) >> 2];
-      const int npos = info >> 16;
-      const float* pp = part + (info & 0xffff) * 16 + (m & 3) * 4 + min(jj, 3);
+      const int npos = (gw[r] >> 11) & 31, m = (gw[r] >> 16) & 127, jj = (gw[r] >> 23) & 3;
+      const float* pp = part + (gw[r] & 0x7ff);
       float sum = 0.0f;
       for (int i0 = 0; i0 < npos; i0 += 8) {
         float v[8];
@@ -227,8 +235,9 @@ __device__ __forceinline__ void mel_mfma_4frames(const FrontParams& p, const flo
         static_for<0, 8>([&](auto If) { sum += (i0 + decltype(If)::value < npos) ? v[decltype(If)::value] : 0.0f; });
       }
       float val = log_epilogue(sum, p.log_kind, p.amin, p.db_offset, p.ln_offset);
-      if (p.affine) val = __builtin_fmaf(val, p.aff_scale[min(m, p.n_mels - 1)], p.aff_shift[min(m, p.n_mels - 1)]);
-      if (o < n_out) melrows[o] = val;
+      if (p.affine) val = __builtin_fmaf(val, p.aff_scale[m], p.aff_shift[m]);
+      const int o = 64 * r + lane;
+      if (o < n_out && jj < nvalid) dst[o] = val;
     }
   });
   wave_phase_fence();
@@ -249,6 +258,8 @@ __global__ void __launch_bounds__(G::WAVES * 64, G::WAVES == 8 ? 2 : 1) stft_mel
   float* melaL = smem + p.off_mela;
   int32_t* melbaseL = (int32_t*)(smem + p.off_melbase);
   int32_t* quadposL = (int32_t*)(smem + p.off_quadpos);
+  int32_t* boffL = (int32_t*)(smem + p.off_boff);
+  int32_t* gwL = (int32_t*)(smem + p.off_gw);
   float* S = smem + p.off_wave + wave * p.wave_floats;
   float* X = S + p.xoff;
 
@@ -261,7 +272,16 @@ __global__ void __launch_bounds__(G::WAVES * 64, G::WAVES == 8 ? 2 : 1) stft_mel
     for (int i = tid; i < p.n_quads; i += NT) quadposL[i] = p.quadpos[i];
   }
   __syncthreads();
+  if constexpr (!SPEC_OUT) {  // per-lane constants of the mel stage: [set][lane] B-operand offsets, [r][lane] gather words
+    for (int i = tid; i < kMaxMelSets * 64; i += NT) {
+      const int s = i >> 6, ln = i & 63;
+      boffL[i] = (s < p.mel_sets) ? (ln & 3) * G::PP + melbaseL[s * 16 + (ln >> 2)] : 0;
+    }
+    for (int i = tid; i < 8 * 64; i += NT) gwL[i] = mel_gather_word(p, quadposL, i);
+    __syncthreads();
+  }
 
+  SED_STAMP_DECL
   const int n_waves = gridDim.x * G::WAVES;
   for (int chunk = blockIdx.x * G::WAVES + wave; chunk < p.total_chunks; chunk += n_waves) {
     const int b = chunk / p.chunks_per_clip;
@@ -276,11 +296,22 @@ __global__ void __launch_bounds__(G::WAVES * 64, G::WAVES == 8 ? 2 : 1) stft_mel
         stage_span(p, S + p.halo, b, s0 + p.halo, p.fresh, lane);
       }
       wave_phase_fence();
+      SED_STAMP(0)
       LaneState<G> st;
       if (!SED_SKIP(p, 2)) lane_stage1<G>(st, S + fi * p.hop, winL, tw1L, l);
       wave_phase_fence();
+      SED_STAMP(1)
       if (p.reuse_halo && !SED_SKIP(p, 4))  // the samples shared with the next FPW frames move to the front of the region
-        for (int i = 4 * lane; i < p.halo; i += 256) st4(S + i, ld4(S + p.fresh + i));
+        for (int i0 = 0; i0 < p.halo; i0 += 4 * 256) {  // batches of 4 x 16 B per lane: reads first, then writes
+          f4 h[4];
+          static_for<0, 4>([&](auto Kf) {
+            h[decltype(Kf)::value] = ld4(S + p.fresh + min(i0 + 256 * decltype(Kf)::value + 4 * lane, p.halo - 4));
+          });
+          static_for<0, 4>([&](auto Kf) {
+            st4(S + min(i0 + 256 * decltype(Kf)::value + 4 * lane, p.halo - 4), h[decltype(Kf)::value]);
+          });
+        }
+      SED_STAMP(2)
       float* xfr = X + fi * G::XFR;
       if (!SED_SKIP(p, 8)) {
         lane_xwrite<G, 0>(st, xfr, l);
@@ -292,12 +323,14 @@ __global__ void __launch_bounds__(G::WAVES * 64, G::WAVES == 8 ? 2 : 1) stft_mel
         lane_xread<G, 1>(st, xfr, l);
         wave_phase_fence();
       }
+      SED_STAMP(3)
       float* pw = X + fi * G::PP;
       int slot_stride = lane_slot_stride<G>(l);
       asm volatile("" : "+v"(slot_stride));  // opaque: per-slot addresses are formed here, not kept in registers
       if (!SED_SKIP(p, 16)) lane_stage2_power<G, MAG>(st, pw, tw2L, l, slot_stride);
       if (l == 0) { pw[G::NBINS] = 0.0f; pw[G::NBINS + 1] = 0.0f; pw[G::NBINS + 2] = 0.0f; }
       wave_phase_fence();
+      SED_STAMP(4)
       const int nvalid = min(G::FPW, f_end - f0);
       if constexpr (SPEC_OUT) {
         float* dst = p.out + (int64_t)b * p.out_stride_b + (int64_t)f0 * G::NBINS;
@@ -305,16 +338,19 @@ __global__ void __launch_bounds__(G::WAVES * 64, G::WAVES == 8 ? 2 : 1) stft_mel
           for (int k = lane; k < G::NBINS; k += 64) dst[(int64_t)f * G::NBINS + k] = X[f * G::PP + k];
       } else {
         float* part = X + G::FPW * G::PP;
-        float* melrows = part + p.mel_sets * 256;
-        for (int g = 0; g < G::FPW / 4; ++g)
-          mel_mfma_4frames<G::PP>(p, X + 4 * g * G::PP, melaL, melbaseL, quadposL, part, melrows + 4 * g * p.n_mels, lane);
         float* dst = p.out + (int64_t)b * p.out_stride_b + (int64_t)f0 * p.n_mels;
-        const int n = SED_SKIP(p, 128) ? 0 : nvalid * p.n_mels;
-        for (int i = lane; i < n; i += 64) dst[i] = melrows[i];
+        for (int g = 0; g < G::FPW / 4; ++g)
+          mel_mfma_4frames<8>(p, boffL, gwL, X + 4 * g * G::PP, melaL, part, dst + 4 * g * p.n_mels, nvalid - 4 * g, lane);
+        SED_STAMP(5)
       }
       wave_phase_fence();
+      SED_STAMP(6)
     }
   }
+#ifdef SED_STAMPS
+  if (lane == 0 && p.stamps)
+    for (int k = 0; k < 8; ++k) p.stamps[(size_t)(blockIdx.x * G::WAVES + wave) * 8 + k] = st_acc[k];
+#endif
 }
 
 // ---- mel projection + log of a materialised spectrogram (LogmelFilterBank.forward) -------------------------
@@ -607,7 +643,7 @@ static int launch_front(const sed_plan* pl, FrontParams p, int64_t B, hipStream_
   p.halo = G::NFFT - p.hop;
   p.reuse_halo = (p.halo > 0 && p.fresh >= p.halo) ? 1 : 0;
   p.xoff = p.reuse_halo ? round64(p.halo) : 0;
-  const int after_rows = SPEC_OUT ? 0 : p.mel_sets * 256 + G::FPW * p.n_mels;
+  const int after_rows = SPEC_OUT ? 0 : p.mel_sets * 256 + 8 * 16;  // partial sums (+ slack for the fixed-size gather)
   const int xwf = round4(std::max(G::FPW * G::XFR, G::FPW * G::PP + after_rows));
   p.wave_floats = round64(std::max(p.span, p.xoff + xwf));
   // shared tables
@@ -618,6 +654,8 @@ static int launch_front(const sed_plan* pl, FrontParams p, int64_t B, hipStream_
   p.off_mela = off; off += SPEC_OUT ? 0 : p.mel_sets * p.mel_u * 256;
   p.off_melbase = off; off += SPEC_OUT ? 0 : round4(p.mel_sets * 16);
   p.off_quadpos = off; off += SPEC_OUT ? 0 : round4(p.n_quads);
+  p.off_boff = off; off += SPEC_OUT ? 0 : kMaxMelSets * 64;
+  p.off_gw = off; off += SPEC_OUT ? 0 : 8 * 64;
   p.off_wave = round64(off);
   const size_t lds_bytes = (size_t)(p.off_wave + G::WAVES * p.wave_floats) * sizeof(float);
   if (lds_bytes > 160 * 1024) return SED_ERR_BAD_ARG;
@@ -640,8 +678,29 @@ static int launch_front(const sed_plan* pl, FrontParams p, int64_t B, hipStream_
   if (total_chunks > INT32_MAX / 2) return SED_ERR_BAD_ARG;
   p.total_chunks = (int32_t)total_chunks;
   const int blocks = (int)std::min<int64_t>((total_chunks + G::WAVES - 1) / G::WAVES, (int64_t)pl->num_cus * per_cu);
+#ifdef SED_STAMPS
+  static unsigned long long* d_stamps = nullptr;
+  const size_t n_st = (size_t)blocks * G::WAVES * 8;
+  if (!d_stamps) (void)hipMalloc((void**)&d_stamps, 4096 * 8 * 8 * sizeof(unsigned long long));
+  p.stamps = d_stamps;
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(G::WAVES * 64), lds_bytes, stream, p);
+  static int calls = 0;
+  if (++calls == 20) {
+    (void)hipDeviceSynchronize();
+    std::vector<unsigned long long> h(n_st);
+    (void)hipMemcpy(h.data(), d_stamps, n_st * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    double sum[8] = {0};
+    for (size_t w = 0; w < n_st / 8; ++w) for (int k = 0; k < 8; ++k) sum[k] += (double)h[w * 8 + k];
+    const char* names[8] = {"stage(global->LDS)", "stage1 fft+twiddle", "halo move", "exchange", "stage2+power", "mel (mfma+gather+log)", "store", "-"};
+    double tot = 0; for (int k = 0; k < 8; ++k) tot += sum[k];
+    for (int k = 0; k < 7; ++k) fprintf(stderr, "STAMP %-24s %10.0f cycles/wave  %5.1f%%\n", names[k], sum[k] / (n_st / 8), 100.0 * sum[k] / tot);
+    fprintf(stderr, "STAMP total %10.0f cycles/wave over %zu waves\n", tot / (n_st / 8), n_st / 8);
+  }
+  return hip_status(hipGetLastError());
+#else
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(G::WAVES * 64), lds_bytes, stream, p);
   return hip_status(hipGetLastError());
+#endif
 }
 
 template <bool SPEC_OUT>

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsedhip.so")
+LIB_PATH = os.environ.get("SED_HIP_LIB") or os.path.join(_HERE, "libsedhip.so")  # override = diagnostic builds
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
