@@ -123,7 +123,7 @@ struct Geo {
   static constexpr int FPI = WAVES * FPW;   // frames per workgroup iteration
   static constexpr int RP = R1 + 4;         // exchange row pitch in floats (R1/2 complex + pad)
   static constexpr int XFR = R2 * RP + 32;  // exchange floats per frame
-  static constexpr int PP = NC + 4;         // power-row pitch in floats
+  static constexpr int PP = NC + 16;        // power-row pitch in floats (16 mod 64: the 4 frames of a wave tile the banks)
   static constexpr int SLOTS = R2 + 1;      // split slots per lane (the last one is used by lane 0 only)
   static_assert(R1 == 2 * LPF, "two stage-2 FFTs per lane");
   static_assert(A == 1 || A == 2, "one or two stage-1 FFTs per lane");
@@ -137,22 +137,49 @@ struct LaneState {
   float qr[G::R2], qi[G::R2];              // stage-2 FFT for k1 = R1 - l   (lane 0: k1 = R1/2)
 };
 
+// Sample sources for stage 1: fp32 PCM (LDS or global memory) and int16 PCM (divided by `div`, as the
+// int16 -> fp32 conversion of the reference does).  Offsets are in samples from the frame's first sample and are
+// multiples of the access width.
+struct SrcF32 {
+  const float* p;
+  SED_HD f2 load2(int o) const { return ld2(p + o); }
+  SED_HD f4 load4(int o) const { return ld4(p + o); }
+};
+struct alignas(4) i16x2 {
+  short x, y;
+};
+struct alignas(8) i16x4 {
+  short x, y, z, w;
+};
+struct SrcI16 {
+  const short* p;
+  float div;
+  SED_HD f2 load2(int o) const {
+    const i16x2 v = *reinterpret_cast<const i16x2*>(p + o);
+    return f2{(float)v.x / div, (float)v.y / div};
+  }
+  SED_HD f4 load4(int o) const {
+    const i16x4 v = *reinterpret_cast<const i16x4*>(p + o);
+    return f4{(float)v.x / div, (float)v.y / div, (float)v.z / div, (float)v.w / div};
+  }
+};
+
 // Stage 1 for lane l of a frame: load + window, R1-point FFT(s), inter-stage twiddle.
-// frame: the frame's NFFT samples; win: NFFT window values (already holding the factor 1/2);
+// src: the frame's NFFT samples; win: NFFT window values (already holding the factor 1/2);
 // tw1[k1*R2 + n2] = W_NC^(n2*k1).
-template <class G>
-SED_HD void lane_stage1(LaneState<G>& st, const float* frame, const float* win, const cplx* tw1, int l) {
+template <class G, class Src>
+SED_HD void lane_stage1(LaneState<G>& st, const Src src, const float* win, const cplx* tw1, int l) {
   constexpr int LOG1 = ilog2(G::R1);
   static_for<0, G::R1>([&](auto N1) {
     constexpr int n1 = decltype(N1)::value;
     constexpr int pos = bitrev(n1, LOG1);
     if constexpr (G::A == 1) {
-      const f2 p = ld2(frame + 2 * G::R2 * n1 + 2 * l);
+      const f2 p = src.load2(2 * G::R2 * n1 + 2 * l);
       const f2 w = ld2(win + 2 * G::R2 * n1 + 2 * l);
       st.yr[0][pos] = p.x * w.x;
       st.yi[0][pos] = p.y * w.y;
     } else {
-      const f4 p = ld4(frame + 2 * G::R2 * n1 + 4 * l);
+      const f4 p = src.load4(2 * G::R2 * n1 + 4 * l);
       const f4 w = ld4(win + 2 * G::R2 * n1 + 4 * l);
       st.yr[0][pos] = p.x * w.x;
       st.yi[0][pos] = p.y * w.y;

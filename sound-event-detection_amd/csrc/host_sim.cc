@@ -23,7 +23,7 @@ double run_one(unsigned seed, int win_length, bool left) {
   const auto tw2 = build_tw2<G>();
   std::vector<LaneState<G>> st(G::LPF);
   std::vector<float> xfr(G::XFR, 0.0f), pw(G::PP, -1.0f);
-  for (int l = 0; l < G::LPF; ++l) lane_stage1<G>(st[l], frame.data(), win.data(), tw1.data(), l);
+  for (int l = 0; l < G::LPF; ++l) lane_stage1<G>(st[l], SrcF32{frame.data()}, win.data(), tw1.data(), l);
   for (int l = 0; l < G::LPF; ++l) lane_xwrite<G, 0>(st[l], xfr.data(), l);
   for (int l = 0; l < G::LPF; ++l) lane_xread<G, 0>(st[l], xfr.data(), l);
   for (int l = 0; l < G::LPF; ++l) lane_xwrite<G, 1>(st[l], xfr.data(), l);
@@ -95,9 +95,9 @@ int main() {
     if (!(e < 2e-6)) bad = 1;
   };
   for (unsigned seed = 1; seed <= 3; ++seed) {
-    report(512, "magnitude/left400", run_one<Geo<16, 16, 8, 8>, true>(seed, 400, true));
-    report(512, "power", run_one<Geo<16, 16, 8, 8>, false>(seed, 512, false));
-    report(1024, "power", run_one<Geo<32, 16, 16, 8>, false>(seed, 1024, false));
+    report(512, "magnitude/left400", run_one<Geo<16, 16, 8, 12>, true>(seed, 400, true));
+    report(512, "power", run_one<Geo<16, 16, 8, 12>, false>(seed, 512, false));
+    report(1024, "power", run_one<Geo<32, 16, 16, 12>, false>(seed, 1024, false));
     report(2048, "magnitude", run_one<Geo<32, 32, 16, 4>, true>(seed, 2048, false));
     report(2048, "power", run_one<Geo<32, 32, 16, 4>, false>(seed, 2048, false));
   }

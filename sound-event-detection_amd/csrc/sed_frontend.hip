@@ -22,11 +22,12 @@
 
 namespace sed {
 
-using Geo512 = Geo<16, 16, 8, 8>;
-using Geo1024 = Geo<32, 16, 16, 8>;
+using Geo512 = Geo<16, 16, 8, 12>;
+using Geo1024 = Geo<32, 16, 16, 12>;
 using Geo2048 = Geo<32, 32, 16, 4>;
 
 constexpr int kMaxMelSets = 4;
+constexpr int kPartStride = 20;  // floats between the partial sums of consecutive positions: [frame][filter] + pad (4*odd: bank spread)
 
 // Timing ablations: build with -DSED_ABLATION and set SED_DEBUG_SKIP=<mask> to leave phases of the streaming loop
 // out (results are then garbage).  In normal builds the tests below fold to false.
@@ -36,9 +37,7 @@ constexpr int kMaxMelSets = 4;
 #define SED_SKIP(p, bit) false
 #endif
 typedef float f4v __attribute__((ext_vector_type(4)));
-struct alignas(8) i16x4 {
-  int16_t x, y, z, w;
-};
+
 
 struct FrontParams {
   const void* pcm;
@@ -49,9 +48,9 @@ struct FrontParams {
   int32_t n_mels, log_kind, affine;
   float amin, db_offset, ln_offset, inv_n_mels;
   int32_t chunk_frames, chunks_per_clip, total_chunks;
-  // per-wave LDS region, in floats: [0, span) PCM span of FPW frames; X = region + xoff holds, in turn, the
-  // exchange rows, then [power rows | mel partial sums | mel rows]
-  int32_t span, halo, fresh, reuse_halo, xoff, wave_floats;
+  // per-wave LDS region, in floats: exchange rows, then [power rows | mel partial sums]; frames at clip edges
+  // (padding) or in unaligned clips are first staged here, span floats for FPW frames
+  int32_t span, direct, wave_floats;
   // LDS carve of the shared tables, in floats
   int32_t off_win, off_tw1, off_tw2, off_mela, off_melbase, off_quadpos, off_boff, off_gw, off_wave;
   int32_t mel_sets, mel_u, mel_maxpos, n_quads;
@@ -165,7 +164,7 @@ __device__ __forceinline__ int mel_gather_word(const FrontParams& p, const int32
   o = min(o, 4 * p.n_mels - 1);
   const int jj = o / p.n_mels, m = o - jj * p.n_mels;
   const int info = quadpos[m >> 2];
-  return ((info & 0xffff) * 16 + (m & 3) * 4 + jj) | ((info >> 16) << 11) | (m << 16) | (jj << 23);
+  return ((info & 0xffff) * kPartStride + jj * 4 + (m & 3)) | ((info >> 16) << 11) | (m << 16) | (jj << 23);
 }
 
 // Mel projection of 4 frames (power rows prow0 + j*PITCH, j = 0..3) on the matrix pipe, then log/affine, then the
@@ -173,7 +172,7 @@ __device__ __forceinline__ int mel_gather_word(const FrontParams& p, const int32
 // Lane 4*block + j feeds the power of frame j as the B operand and the weight of filter 4*quad + j as the
 // A operand of block `block`; after the last instruction it holds, in acc[set][i], the partial sum of filter
 // 4*quad + i for frame j over the bins of position (set, block).  Each set's operands are fetched with one
-// burst of LDS reads; the partial sums of a filter are combined through LDS (they sit 16 floats apart).
+// burst of LDS reads; the partial sums of a filter are combined through LDS (kPartStride floats apart).
 template <int UMAX>
 __device__ __forceinline__ void mel_mfma_4frames(const FrontParams& p, const int32_t* boffL, const int32_t* gwL,
                                                  const float* prow0, const float* mela, float* part, float* dst,
@@ -217,8 +216,7 @@ __device__ __forceinline__ void mel_mfma_4frames(const FrontParams& p, const int
   static_for<0, kMaxMelSets>([&](auto Sf) {
     constexpr int s = decltype(Sf)::value;
     if (s < p.mel_sets) {
-      float* d = part + (s * 16 + blk) * 16 + j;
-      d[0] = acc[s][0]; d[4] = acc[s][1]; d[8] = acc[s][2]; d[12] = acc[s][3];
+      st4(part + (s * 16 + blk) * kPartStride + j * 4, f4{acc[s][0], acc[s][1], acc[s][2], acc[s][3]});
     }
   });
   wave_phase_fence();
@@ -231,7 +229,7 @@ __device__ __forceinline__ void mel_mfma_4frames(const FrontParams& p, const int
       float sum = 0.0f;
       for (int i0 = 0; i0 < npos; i0 += 8) {
         float v[8];
-        static_for<0, 8>([&](auto If) { v[decltype(If)::value] = pp[(i0 + decltype(If)::value) * 16]; });
+        static_for<0, 8>([&](auto If) { v[decltype(If)::value] = pp[(i0 + decltype(If)::value) * kPartStride]; });
         static_for<0, 8>([&](auto If) { sum += (i0 + decltype(If)::value < npos) ? v[decltype(If)::value] : 0.0f; });
       }
       float val = log_epilogue(sum, p.log_kind, p.amin, p.db_offset, p.ln_offset);
@@ -244,7 +242,7 @@ __device__ __forceinline__ void mel_mfma_4frames(const FrontParams& p, const int
 }
 
 template <class G, bool MAG, bool SPEC_OUT>
-__global__ void __launch_bounds__(G::WAVES * 64, G::WAVES == 8 ? 2 : 1) stft_mel_kernel(const FrontParams p) {
+__global__ void __launch_bounds__(G::WAVES * 64, G::WAVES / 4) stft_mel_kernel(const FrontParams p) {
   extern __shared__ __align__(16) float smem[];
   constexpr int NT = G::WAVES * 64;
   const int tid = threadIdx.x;
@@ -260,8 +258,7 @@ __global__ void __launch_bounds__(G::WAVES * 64, G::WAVES == 8 ? 2 : 1) stft_mel
   int32_t* quadposL = (int32_t*)(smem + p.off_quadpos);
   int32_t* boffL = (int32_t*)(smem + p.off_boff);
   int32_t* gwL = (int32_t*)(smem + p.off_gw);
-  float* S = smem + p.off_wave + wave * p.wave_floats;
-  float* X = S + p.xoff;
+  float* X = smem + p.off_wave + wave * p.wave_floats;
 
   for (int i = tid; i < G::NFFT; i += NT) winL[i] = p.window[i];
   for (int i = tid; i < G::R1 * G::R2; i += NT) tw1L[i] = p.tw1[i];
@@ -289,29 +286,20 @@ __global__ void __launch_bounds__(G::WAVES * 64, G::WAVES == 8 ? 2 : 1) stft_mel
     const int f_end = min(p.T, f_begin + p.chunk_frames);
     for (int f0 = f_begin; f0 < f_end; f0 += G::FPW) {
       const int64_t s0 = (int64_t)f0 * p.hop - p.pad_left;
-      if (SED_SKIP(p, 1)) {
-      } else if (f0 == f_begin || !p.reuse_halo) {
-        stage_span(p, S, b, s0, p.span, lane);
+      LaneState<G> st;
+      // Interior frames of aligned clips are read straight from global memory: each lane fetches its own samples
+      // (8 or 16 B per load, R1 independent loads in flight), the overlap between frames is served by L1/L2.
+      if (p.direct && s0 >= 0 && s0 + p.span <= p.L) {
+        const int64_t first = (int64_t)b * p.pcm_stride + s0 + fi * p.hop;
+        if (p.pcm_kind == SED_PCM_F32) lane_stage1<G>(st, SrcF32{(const float*)p.pcm + first}, winL, tw1L, l);
+        else lane_stage1<G>(st, SrcI16{(const short*)p.pcm + first, p.pcm_div}, winL, tw1L, l);
       } else {
-        stage_span(p, S + p.halo, b, s0 + p.halo, p.fresh, lane);
+        stage_span(p, X, b, s0, p.span, lane);
+        wave_phase_fence();
+        lane_stage1<G>(st, SrcF32{X + fi * p.hop}, winL, tw1L, l);
       }
       wave_phase_fence();
-      SED_STAMP(0)
-      LaneState<G> st;
-      if (!SED_SKIP(p, 2)) lane_stage1<G>(st, S + fi * p.hop, winL, tw1L, l);
-      wave_phase_fence();
       SED_STAMP(1)
-      if (p.reuse_halo && !SED_SKIP(p, 4))  // the samples shared with the next FPW frames move to the front of the region
-        for (int i0 = 0; i0 < p.halo; i0 += 4 * 256) {  // batches of 4 x 16 B per lane: reads first, then writes
-          f4 h[4];
-          static_for<0, 4>([&](auto Kf) {
-            h[decltype(Kf)::value] = ld4(S + p.fresh + min(i0 + 256 * decltype(Kf)::value + 4 * lane, p.halo - 4));
-          });
-          static_for<0, 4>([&](auto Kf) {
-            st4(S + min(i0 + 256 * decltype(Kf)::value + 4 * lane, p.halo - 4), h[decltype(Kf)::value]);
-          });
-        }
-      SED_STAMP(2)
       float* xfr = X + fi * G::XFR;
       if (!SED_SKIP(p, 8)) {
         lane_xwrite<G, 0>(st, xfr, l);
@@ -328,7 +316,7 @@ __global__ void __launch_bounds__(G::WAVES * 64, G::WAVES == 8 ? 2 : 1) stft_mel
       int slot_stride = lane_slot_stride<G>(l);
       asm volatile("" : "+v"(slot_stride));  // opaque: per-slot addresses are formed here, not kept in registers
       if (!SED_SKIP(p, 16)) lane_stage2_power<G, MAG>(st, pw, tw2L, l, slot_stride);
-      if (l == 0) { pw[G::NBINS] = 0.0f; pw[G::NBINS + 1] = 0.0f; pw[G::NBINS + 2] = 0.0f; }
+      for (int k = G::NBINS + l; k < G::PP; k += G::LPF) pw[k] = 0.0f;  // row padding read (with zero weight) by the mel stage
       wave_phase_fence();
       SED_STAMP(4)
       const int nvalid = min(G::FPW, f_end - f0);
@@ -337,7 +325,7 @@ __global__ void __launch_bounds__(G::WAVES * 64, G::WAVES == 8 ? 2 : 1) stft_mel
         for (int f = 0; f < nvalid; ++f)
           for (int k = lane; k < G::NBINS; k += 64) dst[(int64_t)f * G::NBINS + k] = X[f * G::PP + k];
       } else {
-        float* part = X + G::FPW * G::PP;
+        float* part = X;  // the partial sums overlay the first 4 power rows, which the MFMAs have consumed by then
         float* dst = p.out + (int64_t)b * p.out_stride_b + (int64_t)f0 * p.n_mels;
         for (int g = 0; g < G::FPW / 4; ++g)
           mel_mfma_4frames<8>(p, boffL, gwL, X + 4 * g * G::PP, melaL, part, dst + 4 * g * p.n_mels, nvalid - 4 * g, lane);
@@ -639,13 +627,10 @@ template <class G, bool MAG, bool SPEC_OUT>
 static int launch_front(const sed_plan* pl, FrontParams p, int64_t B, hipStream_t stream) {
   // per-wave LDS region
   p.span = (G::FPW - 1) * p.hop + G::NFFT;
-  p.fresh = G::FPW * p.hop;
-  p.halo = G::NFFT - p.hop;
-  p.reuse_halo = (p.halo > 0 && p.fresh >= p.halo) ? 1 : 0;
-  p.xoff = p.reuse_halo ? round64(p.halo) : 0;
-  const int after_rows = SPEC_OUT ? 0 : p.mel_sets * 256 + 8 * 16;  // partial sums (+ slack for the fixed-size gather)
-  const int xwf = round4(std::max(G::FPW * G::XFR, G::FPW * G::PP + after_rows));
-  p.wave_floats = round64(std::max(p.span, p.xoff + xwf));
+  p.direct = p.vec_ok;
+  const int part_floats = SPEC_OUT ? 0 : (p.mel_sets * 16 + 8) * kPartStride;  // partial sums + slack for the fixed-size gather
+  const int xwf = round4(std::max(std::max(G::FPW * G::XFR, G::FPW * G::PP), part_floats));
+  p.wave_floats = round64(std::max(p.span, xwf));
   // shared tables
   int off = 0;
   p.off_win = off; off += G::NFFT;
