@@ -14,6 +14,10 @@
 
 #include <type_traits>
 
+#if !defined(__clang__)
+#error "fft_core.h uses clang vector extensions: build with hipcc, or ROCm's clang++ for host-only programs"
+#endif
+
 #if defined(__HIPCC__)
 #define SED_HD __host__ __device__ __forceinline__
 #else
@@ -26,16 +30,38 @@ struct alignas(8) cplx {
   float x, y;
 };
 
+// A complex value (re, im) in one aligned register pair.  gfx950 executes add/mul/fma on such pairs in one
+// instruction (v_pk_*_f32) and can swap or broadcast the halves of each operand for free, so every step below
+// is written on pairs; on the host the same expressions evaluate element by element with the same roundings.
+typedef float v2 __attribute__((ext_vector_type(2)));
+typedef float v4 __attribute__((ext_vector_type(4)));
+
 // 8- and 16-byte accesses: the pointer handed to ld2/ld4/st4 must be aligned to the access size.
-struct alignas(8) f2 {
-  float x, y;
-};
-struct alignas(16) f4 {
-  float x, y, z, w;
-};
-SED_HD f2 ld2(const float* p) { return *reinterpret_cast<const f2*>(p); }
-SED_HD f4 ld4(const float* p) { return *reinterpret_cast<const f4*>(p); }
-SED_HD void st4(float* p, f4 v) { *reinterpret_cast<f4*>(p) = v; }
+SED_HD v2 ld2(const float* p) { return *reinterpret_cast<const v2*>(p); }
+SED_HD v2 ld2(const cplx* p) { return *reinterpret_cast<const v2*>(p); }
+SED_HD v4 ld4(const float* p) { return *reinterpret_cast<const v4*>(p); }
+SED_HD void st4(float* p, v4 v) { *reinterpret_cast<v4*>(p) = v; }
+
+SED_HD v2 pk_fma(v2 a, v2 b, v2 c) { return __builtin_elementwise_fma(a, b, c); }
+SED_HD v2 swp(v2 a) { return __builtin_shufflevector(a, a, 1, 0); }
+SED_HD v2 lo2(v2 a) { return __builtin_shufflevector(a, a, 0, 0); }
+SED_HD v2 hi2(v2 a) { return __builtin_shufflevector(a, a, 1, 1); }
+// By-value select: a conditional between two lvalues would select between their ADDRESSES, which keeps
+// register arrays in scratch memory.
+SED_HD v2 select(bool c, v2 a, v2 b) { return c ? a : b; }
+
+// Complex product y * w: (yx wx - yy wy, yx wy + yy wx) as one packed multiply and one packed fma whose second
+// operand is w with its halves swapped and the low half negated (operand modifiers of the instruction).
+SED_HD v2 cmul(v2 y, v2 w) {
+  const v2 t = lo2(y) * w;
+#if defined(__HIP_DEVICE_COMPILE__)
+  v2 d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(d) : "v"(y), "v"(w), "v"(t));
+  return d;
+#else
+  return v2{__builtin_fmaf(-y.y, w.y, t.x), __builtin_fmaf(y.y, w.x, t.y)};
+#endif
+}
 
 template <int I, int N, class F>
 SED_HD void static_for(F&& f) {
@@ -44,10 +70,6 @@ SED_HD void static_for(F&& f) {
     static_for<I + 1, N>(f);
   }
 }
-
-// By-value select: a conditional between two lvalues would select between their ADDRESSES, which keeps
-// register arrays in scratch memory.
-SED_HD float select(bool c, float a, float b) { return c ? a : b; }
 
 constexpr int ilog2(int n) { return n <= 1 ? 0 : 1 + ilog2(n >> 1); }
 constexpr int bitrev(int v, int bits) {
@@ -66,41 +88,29 @@ constexpr float kSin32[16] = {0.0f, 0.19509032201612828f, 0.3826834323650898f, 0
                               1.0f, 0.9807852804032304f, 0.9238795325112867f, 0.8314696123025452f,
                               0.7071067811865476f, 0.5555702330196022f, 0.3826834323650898f, 0.19509032201612828f};
 
-// One decimation-in-time butterfly (a, b) -> (a + w b, a - w b) with w = W_32^TW.
-// The general case forms a + w b with four fused multiply-adds and a - w b as 2a - (a + w b).
+// One decimation-in-time butterfly (a, b) -> (a + w b, a - w b) with w = W_32^TW = c - i s.
+// General case: a + w b = (a + c b) + (s, -s) * swap(b) in two packed fmas, a - w b = 2a - (a + w b) in a third.
 template <int TW>
-SED_HD void butterfly(float& ar, float& ai, float& br, float& bi) {
+SED_HD void butterfly(v2& a, v2& b) {
   if constexpr (TW == 0) {
-    const float tr = br, ti = bi;
-    br = ar - tr; bi = ai - ti;
-    ar = ar + tr; ai = ai + ti;
+    const v2 t = b;
+    b = a - t;
+    a = a + t;
   } else if constexpr (TW == 8) {  // w = -i : w b = (bi, -br)
-    const float tr = bi, ti = br;
-    br = ar - tr; bi = ai + ti;
-    ar = ar + tr; ai = ai - ti;
-  } else if constexpr (TW == 4) {  // w = (1 - i)/sqrt2 : w b = s (br + bi, bi - br)
-    constexpr float s = 0.7071067811865476f;
-    const float p = br + bi, q = bi - br;
-    br = __builtin_fmaf(-s, p, ar); bi = __builtin_fmaf(-s, q, ai);
-    ar = __builtin_fmaf(s, p, ar);  ai = __builtin_fmaf(s, q, ai);
-  } else if constexpr (TW == 12) {  // w = (-1 - i)/sqrt2 : w b = s (bi - br, -(br + bi))
-    constexpr float s = 0.7071067811865476f;
-    const float p = bi - br, q = br + bi;
-    br = __builtin_fmaf(-s, p, ar); bi = __builtin_fmaf(s, q, ai);
-    ar = __builtin_fmaf(s, p, ar);  ai = __builtin_fmaf(-s, q, ai);
+    const v2 t = swp(b), k = v2{1.0f, -1.0f};
+    b = pk_fma(t, -k, a);
+    a = pk_fma(t, k, a);
   } else {
-    constexpr float c = kCos32[TW], s = kSin32[TW];  // w = c - i s : w b = (c br + s bi, c bi - s br)
-    const float nr = __builtin_fmaf(s, bi, __builtin_fmaf(c, br, ar));
-    const float ni = __builtin_fmaf(-s, br, __builtin_fmaf(c, bi, ai));
-    br = __builtin_fmaf(2.0f, ar, -nr);
-    bi = __builtin_fmaf(2.0f, ai, -ni);
-    ar = nr; ai = ni;
+    constexpr float c = kCos32[TW], s = kSin32[TW];
+    const v2 n = pk_fma(swp(b), v2{s, -s}, pk_fma(b, v2{c, c}, a));
+    b = pk_fma(a, v2{2.0f, 2.0f}, -n);
+    a = n;
   }
 }
 
 // In-register N-point FFT (N = 2..32, power of two).  Input in bit-reversed order, output in natural order.
 template <int N>
-SED_HD void fft_dit(float (&xr)[N], float (&xi)[N]) {
+SED_HD void fft_dit(v2 (&x)[N]) {
   constexpr int LOG = ilog2(N);
   static_for<0, LOG>([&](auto S) {
     constexpr int h = 1 << decltype(S)::value;  // half span of this stage
@@ -109,7 +119,7 @@ SED_HD void fft_dit(float (&xr)[N], float (&xi)[N]) {
       constexpr int g = b / h, j = b % h;
       constexpr int i0 = g * 2 * h + j, i1 = i0 + h;
       constexpr int tw = j * (16 / h);  // W_{2h}^j = W_32^{j*16/h}
-      butterfly<tw>(xr[i0], xi[i0], xr[i1], xi[i1]);
+      butterfly<tw>(x[i0], x[i1]);
     });
   });
 }
@@ -124,7 +134,7 @@ struct Geo {
   static constexpr int RP = R1 + 4;         // exchange row pitch in floats (R1/2 complex + pad)
   static constexpr int XFR = R2 * RP + 32;  // exchange floats per frame
   static constexpr int PP = NC + 16;        // power-row pitch in floats (16 mod 64: the 4 frames of a wave tile the banks)
-  static constexpr int SLOTS = R2 + 1;      // split slots per lane (the last one is used by lane 0 only)
+  static constexpr int SLOTS = R2 + 1;      // split slots per lane (one of them stores from lane 0 only)
   static_assert(R1 == 2 * LPF, "two stage-2 FFTs per lane");
   static_assert(A == 1 || A == 2, "one or two stage-1 FFTs per lane");
   static_assert(R1 <= 32 && R2 <= 32, "twiddle literals cover N <= 32");
@@ -132,9 +142,9 @@ struct Geo {
 
 template <class G>
 struct LaneState {
-  float yr[G::A][G::R1], yi[G::A][G::R1];  // stage-1 data, natural k1 order after the FFT
-  float pr[G::R2], pi[G::R2];              // stage-2 FFT for k1 = l        (lane 0: k1 = 0)
-  float qr[G::R2], qi[G::R2];              // stage-2 FFT for k1 = R1 - l   (lane 0: k1 = R1/2)
+  v2 y[G::A][G::R1];  // stage-1 data, natural k1 order after the FFT
+  v2 p[G::R2];        // stage-2 FFT for k1 = l        (lane 0: k1 = 0)
+  v2 q[G::R2];        // stage-2 FFT for k1 = R1 - l   (lane 0: k1 = R1/2)
 };
 
 // Sample sources for stage 1: fp32 PCM (LDS or global memory) and int16 PCM (divided by `div`, as the
@@ -142,8 +152,8 @@ struct LaneState {
 // multiples of the access width.
 struct SrcF32 {
   const float* p;
-  SED_HD f2 load2(int o) const { return ld2(p + o); }
-  SED_HD f4 load4(int o) const { return ld4(p + o); }
+  SED_HD v2 load2(int o) const { return ld2(p + o); }
+  SED_HD v4 load4(int o) const { return ld4(p + o); }
 };
 struct alignas(4) i16x2 {
   short x, y;
@@ -154,13 +164,13 @@ struct alignas(8) i16x4 {
 struct SrcI16 {
   const short* p;
   float div;
-  SED_HD f2 load2(int o) const {
+  SED_HD v2 load2(int o) const {
     const i16x2 v = *reinterpret_cast<const i16x2*>(p + o);
-    return f2{(float)v.x / div, (float)v.y / div};
+    return v2{(float)v.x / div, (float)v.y / div};
   }
-  SED_HD f4 load4(int o) const {
+  SED_HD v4 load4(int o) const {
     const i16x4 v = *reinterpret_cast<const i16x4*>(p + o);
-    return f4{(float)v.x / div, (float)v.y / div, (float)v.z / div, (float)v.w / div};
+    return v4{(float)v.x / div, (float)v.y / div, (float)v.z / div, (float)v.w / div};
   }
 };
 
@@ -174,29 +184,20 @@ SED_HD void lane_stage1(LaneState<G>& st, const Src src, const float* win, const
     constexpr int n1 = decltype(N1)::value;
     constexpr int pos = bitrev(n1, LOG1);
     if constexpr (G::A == 1) {
-      const f2 p = src.load2(2 * G::R2 * n1 + 2 * l);
-      const f2 w = ld2(win + 2 * G::R2 * n1 + 2 * l);
-      st.yr[0][pos] = p.x * w.x;
-      st.yi[0][pos] = p.y * w.y;
+      st.y[0][pos] = src.load2(2 * G::R2 * n1 + 2 * l) * ld2(win + 2 * G::R2 * n1 + 2 * l);
     } else {
-      const f4 p = src.load4(2 * G::R2 * n1 + 4 * l);
-      const f4 w = ld4(win + 2 * G::R2 * n1 + 4 * l);
-      st.yr[0][pos] = p.x * w.x;
-      st.yi[0][pos] = p.y * w.y;
-      st.yr[1][pos] = p.z * w.z;
-      st.yi[1][pos] = p.w * w.w;
+      const v4 pw = src.load4(2 * G::R2 * n1 + 4 * l) * ld4(win + 2 * G::R2 * n1 + 4 * l);
+      st.y[0][pos] = pw.xy;
+      st.y[1][pos] = pw.zw;
     }
   });
   static_for<0, G::A>([&](auto Af) {
     constexpr int a = decltype(Af)::value;
-    fft_dit<G::R1>(st.yr[a], st.yi[a]);
+    fft_dit<G::R1>(st.y[a]);
     const int n2 = G::A * l + a;
     static_for<1, G::R1>([&](auto K1) {
       constexpr int k1 = decltype(K1)::value;
-      const cplx w = tw1[k1 * G::R2 + n2];
-      const float r = st.yr[a][k1], i = st.yi[a][k1];
-      st.yr[a][k1] = __builtin_fmaf(-i, w.y, r * w.x);
-      st.yi[a][k1] = __builtin_fmaf(i, w.x, r * w.y);
+      st.y[a][k1] = cmul(st.y[a][k1], ld2(tw1 + k1 * G::R2 + n2));
     });
   });
 }
@@ -210,7 +211,7 @@ SED_HD void lane_xwrite(const LaneState<G>& st, float* xfr, int l) {
     static_for<0, G::R1 / 4>([&](auto Q) {
       constexpr int q = decltype(Q)::value;
       constexpr int k1 = PH * (G::R1 / 2) + 2 * q;
-      st4(row + 4 * q, f4{st.yr[a][k1], st.yi[a][k1], st.yr[a][k1 + 1], st.yi[a][k1 + 1]});
+      st4(row + 4 * q, __builtin_shufflevector(st.y[a][k1], st.y[a][k1 + 1], 0, 1, 2, 3));
     });
   });
 }
@@ -229,70 +230,62 @@ SED_HD void lane_xread(LaneState<G>& st, const float* xfr, int l) {
   static_for<0, G::R2>([&](auto N2) {
     constexpr int n2 = decltype(N2)::value;
     constexpr int pos = bitrev(n2, LOG2);
-    const f2 p = ld2(col + n2 * G::RP);
-    if constexpr (PH == 0) {
-      st.pr[pos] = p.x;
-      st.pi[pos] = p.y;
-    } else {
-      st.qr[pos] = p.x;
-      st.qi[pos] = p.y;
-    }
+    if constexpr (PH == 0) st.p[pos] = ld2(col + n2 * G::RP);
+    else st.q[pos] = ld2(col + n2 * G::RP);
   });
 }
 
-// Bin index held in split slot s of lane l (the partner bin is NC - bin): l + s * lane_slot_stride(l).
+// Split slots.  After stage 2 a lane l > 0 holds P[s] = Z[l + R1 s] and Q[s] = Z[(R1 - l) + R1 s]; bin k = l + R1 s
+// pairs with NC - k = Q[R2-1-s].  Lane 0 holds P[s] = Z[R1 s] and Q[s] = Z[R1/2 + R1 s], whose partners are in the
+// same array: P[s] with P[R2-s], Q[s] with Q[R2-1-s].  Slot t of SLOTS = R2 + 1:
+//   t <= R2/2 ("P slot", s = t)    : U = P[s], V = Q[R2-1-s]            (lane 0: V = P[(R2-s) % R2]),  k = l + R1 s
+//   t >  R2/2 ("Q slot", s = t - 1): U = P[s] (lane 0: Q[s]), V = Q[R2-1-s],  k = l + R1 s  (lane 0: + R1/2)
+// so only one operand per slot depends on the lane, every store address is a per-lane base plus a constant, and
+// lane 0 alone stores in slot t = R2/2 + 1 (for the other lanes it repeats slot R2/2).
 template <class G>
-SED_HD int lane_slot_stride(int l) {
-  return l == 0 ? G::R1 / 2 : G::R1;
-}
-template <class G>
-SED_HD int lane_slot_bin(int l, int s) {
-  return l + s * lane_slot_stride<G>(l);
+SED_HD int lane_slot_bin(int l, int t) {
+  const int s = t <= G::R2 / 2 ? t : t - 1;
+  return l + G::R1 * s + ((t > G::R2 / 2 && l == 0) ? G::R1 / 2 : 0);
 }
 
 // Stage-2 FFTs, real-FFT split and |X|^2 (or |X|) into the frame's power row pw[0..NC].
-// tw2[s*LPF + l] = W_NFFT^(lane_slot_bin(l, s)); slot_stride = lane_slot_stride(l), passed in so that a
-// caller inside a loop can keep the per-slot addresses from being precomputed into registers.
+// tw2[t*LPF + l] = W_NFFT^(lane_slot_bin(l, t)).
+// With E = U + conj V, O = -i (U - conj V), T = W O:  X[k] = E + T,  conj X[NC-k] = E - T.
 template <class G, bool MAGNITUDE>
-SED_HD void lane_stage2_power(LaneState<G>& st, float* pw, const cplx* tw2, int l, int slot_stride) {
-  fft_dit<G::R2>(st.pr, st.pi);
-  fft_dit<G::R2>(st.qr, st.qi);
+SED_HD void lane_stage2_power(LaneState<G>& st, float* pw, const cplx* tw2, int l) {
+  fft_dit<G::R2>(st.p);
+  fft_dit<G::R2>(st.q);
   const bool l0 = (l == 0);
-  static_for<0, G::SLOTS>([&](auto Sf) {
-    constexpr int s = decltype(Sf)::value;
-    // lane 0 holds Z[(R1/2) m], m = 0..2*R2-1: even m in P[m/2], odd m in Q[(m-1)/2]
-    constexpr int mu = s, mv = (2 * G::R2 - s) % (2 * G::R2);
-    float u0r, u0i, v0r, v0i;
-    if constexpr (mu % 2 == 0) { u0r = st.pr[mu / 2]; u0i = st.pi[mu / 2]; }
-    else { u0r = st.qr[mu / 2]; u0i = st.qi[mu / 2]; }
-    if constexpr (mv % 2 == 0) { v0r = st.pr[mv / 2]; v0i = st.pi[mv / 2]; }
-    else { v0r = st.qr[mv / 2]; v0i = st.qi[mv / 2]; }
-    float ur, ui, vr, vi;
-    if constexpr (s < G::R2) {
-      ur = select(l0, u0r, st.pr[s]);
-      ui = select(l0, u0i, st.pi[s]);
-      vr = select(l0, v0r, st.qr[G::R2 - 1 - s]);
-      vi = select(l0, v0i, st.qi[G::R2 - 1 - s]);
+  const int off = l0 ? G::R1 / 2 : 0;
+  float* lo_p = pw + l;                 // pw[k] of P slots at lo_p[R1 s]
+  float* lo_q = lo_p + off;             // ... of Q slots
+  float* hi_p = pw + G::R1 - l;         // pw[NC - k] of P slots at hi_p[R1 (R2-1-s)]
+  float* hi_q = hi_p - off;
+  const v2 k = v2{1.0f, -1.0f};
+  static_for<0, G::SLOTS>([&](auto Tf) {
+    constexpr int t = decltype(Tf)::value;
+    constexpr bool qslot = t > G::R2 / 2;
+    constexpr int s = qslot ? t - 1 : t;
+    v2 u, v;
+    if constexpr (!qslot) {
+      u = st.p[s];
+      v = select(l0, st.p[(G::R2 - s) % G::R2], st.q[G::R2 - 1 - s]);
     } else {
-      ur = u0r; ui = u0i; vr = v0r; vi = v0i;
+      u = select(l0, st.q[s], st.p[s]);
+      v = st.q[G::R2 - 1 - s];
     }
-    const cplx w = tw2[s * G::LPF + l];
-    const float er = ur + vr, ei = ui - vi;     // E = U + conj V
-    const float orr = ui + vi, oi = vr - ur;    // O = -i (U - conj V)
-    const float tr = __builtin_fmaf(-oi, w.y, orr * w.x);  // T = W O
-    const float ti = __builtin_fmaf(oi, w.x, orr * w.y);
-    const float ar = er + tr, ai = ei + ti;     // X[k]
-    const float br = er - tr, bi = ei - ti;     // conj X[NC-k]
-    float pa = __builtin_fmaf(ai, ai, ar * ar);
-    float pb = __builtin_fmaf(bi, bi, br * br);
-    if constexpr (MAGNITUDE) {
-      pa = __builtin_sqrtf(pa);
-      pb = __builtin_sqrtf(pb);
-    }
-    const int k = l + s * slot_stride;
-    if (s < G::R2 || l0) {
-      pw[k] = pa;
-      pw[G::NC - k] = pb;
+    const v2 e = pk_fma(v, k, u);             // (ur + vr, ui - vi)
+    const v2 o = pk_fma(swp(u), k, swp(v));   // (ui + vi, vr - ur)
+    const v2 tt = cmul(o, ld2(tw2 + t * G::LPF + l));
+    const v2 re = pk_fma(lo2(tt), k, lo2(e)); // (Re X[k], Re X[NC-k])
+    const v2 im = pk_fma(hi2(tt), k, hi2(e)); // (Im X[k], -Im X[NC-k])
+    v2 pp = pk_fma(im, im, re * re);
+    if constexpr (MAGNITUDE) pp = v2{__builtin_sqrtf(pp.x), __builtin_sqrtf(pp.y)};
+    float* lo = qslot ? lo_q : lo_p;
+    float* hi = qslot ? hi_q : hi_p;
+    if (t != G::R2 / 2 + 1 || l0) {
+      lo[G::R1 * s] = pp.x;
+      hi[G::R1 * (G::R2 - 1 - s)] = pp.y;
     }
   });
 }

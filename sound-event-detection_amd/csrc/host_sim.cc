@@ -28,7 +28,7 @@ double run_one(unsigned seed, int win_length, bool left) {
   for (int l = 0; l < G::LPF; ++l) lane_xread<G, 0>(st[l], xfr.data(), l);
   for (int l = 0; l < G::LPF; ++l) lane_xwrite<G, 1>(st[l], xfr.data(), l);
   for (int l = 0; l < G::LPF; ++l) lane_xread<G, 1>(st[l], xfr.data(), l);
-  for (int l = 0; l < G::LPF; ++l) lane_stage2_power<G, MAG>(st[l], pw.data(), tw2.data(), l, lane_slot_stride<G>(l));
+  for (int l = 0; l < G::LPF; ++l) lane_stage2_power<G, MAG>(st[l], pw.data(), tw2.data(), l);
   double worst = 0.0, scale = 0.0;
   std::vector<double> ref(G::NBINS);
   for (int k = 0; k <= G::NC; ++k) {

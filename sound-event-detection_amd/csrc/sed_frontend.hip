@@ -36,7 +36,6 @@ constexpr int kPartStride = 20;  // floats between the partial sums of consecuti
 #else
 #define SED_SKIP(p, bit) false
 #endif
-typedef float f4v __attribute__((ext_vector_type(4)));
 
 
 struct FrontParams {
@@ -130,7 +129,7 @@ __device__ __forceinline__ void stage_span(const FrontParams& p, float* dst, int
   if (fast && p.pcm_kind == SED_PCM_F32) {
     const float* src = (const float*)p.pcm + b * p.pcm_stride + s0;
     for (int base = 0; base < count; base += 8 * 256) {
-      f4 v[8];
+      v4 v[8];
       static_for<0, 8>([&](auto Kf) {
         v[decltype(Kf)::value] = ld4(src + min(base + 256 * decltype(Kf)::value + 4 * lane, count - 4));
       });
@@ -149,7 +148,7 @@ __device__ __forceinline__ void stage_span(const FrontParams& p, float* dst, int
       static_for<0, 8>([&](auto Kf) {
         const i16x4 w = v[decltype(Kf)::value];
         st4(dst + min(base + 256 * decltype(Kf)::value + 4 * lane, count - 4),
-            f4{(float)w.x / p.pcm_div, (float)w.y / p.pcm_div, (float)w.z / p.pcm_div, (float)w.w / p.pcm_div});
+            v4{(float)w.x / p.pcm_div, (float)w.y / p.pcm_div, (float)w.z / p.pcm_div, (float)w.w / p.pcm_div});
       });
     }
   } else {
@@ -186,15 +185,15 @@ __device__ __forceinline__ void mel_mfma_4frames(const FrontParams& p, const int
     constexpr int r = decltype(Rf)::value;
     gw[r] = (64 * r < 4 * p.n_mels) ? gwL[r * 64 + lane] : 0;
   });
-  f4v acc[kMaxMelSets];
+  v4 acc[kMaxMelSets];
   static_for<0, kMaxMelSets>([&](auto Sf) {
     constexpr int s = decltype(Sf)::value;
-    acc[s] = f4v{0.0f, 0.0f, 0.0f, 0.0f};
+    acc[s] = v4{0.0f, 0.0f, 0.0f, 0.0f};
     if (s < p.mel_sets) {
       const float* bp = prow0 + boff[s];
       const float* ap = mela + ((size_t)s * p.mel_u * 64 + lane) * 4;
       for (int u0 = 0; u0 < p.mel_u; u0 += UMAX) {
-        f4 a[UMAX], b[UMAX];
+        v4 a[UMAX], b[UMAX];
         static_for<0, UMAX>([&](auto Uf) {
           constexpr int k = decltype(Uf)::value;
           const int u = min(u0 + k, p.mel_u - 1);
@@ -216,7 +215,7 @@ __device__ __forceinline__ void mel_mfma_4frames(const FrontParams& p, const int
   static_for<0, kMaxMelSets>([&](auto Sf) {
     constexpr int s = decltype(Sf)::value;
     if (s < p.mel_sets) {
-      st4(part + (s * 16 + blk) * kPartStride + j * 4, f4{acc[s][0], acc[s][1], acc[s][2], acc[s][3]});
+      st4(part + (s * 16 + blk) * kPartStride + j * 4, acc[s]);
     }
   });
   wave_phase_fence();
@@ -313,9 +312,7 @@ __global__ void __launch_bounds__(G::WAVES * 64, G::WAVES / 4) stft_mel_kernel(c
       }
       SED_STAMP(3)
       float* pw = X + fi * G::PP;
-      int slot_stride = lane_slot_stride<G>(l);
-      asm volatile("" : "+v"(slot_stride));  // opaque: per-slot addresses are formed here, not kept in registers
-      if (!SED_SKIP(p, 16)) lane_stage2_power<G, MAG>(st, pw, tw2L, l, slot_stride);
+      if (!SED_SKIP(p, 16)) lane_stage2_power<G, MAG>(st, pw, tw2L, l);
       for (int k = G::NBINS + l; k < G::PP; k += G::LPF) pw[k] = 0.0f;  // row padding read (with zero weight) by the mel stage
       wave_phase_fence();
       SED_STAMP(4)

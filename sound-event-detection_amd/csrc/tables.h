@@ -38,7 +38,7 @@ std::vector<cplx> build_tw1() {  // [k1*R2 + n2] = W_NC^(n2 k1)
 }
 
 template <class G>
-std::vector<cplx> build_tw2() {  // [s*LPF + l] = W_NFFT^(bin of slot s in lane l)
+std::vector<cplx> build_tw2() {  // [t*LPF + l] = W_NFFT^(bin of slot t in lane l)
   std::vector<cplx> t(G::SLOTS * G::LPF);
   for (int s = 0; s < G::SLOTS; ++s)
     for (int l = 0; l < G::LPF; ++l) t[s * G::LPF + l] = unit_root(lane_slot_bin<G>(l, s), G::NFFT);
