@@ -47,12 +47,12 @@ struct FrontParams {
   int32_t n_mels, log_kind, affine;
   float amin, db_offset, ln_offset, inv_n_mels;
   int32_t chunk_frames, chunks_per_clip, total_chunks;
-  // per-wave LDS region, in floats: exchange rows, then [power rows | mel partial sums]; frames at clip edges
-  // (padding) or in unaligned clips are first staged here, span floats for FPW frames
-  int32_t span, direct, wave_floats;
+  // per-wave LDS region, in floats: [exchange rows | power rows, then mel partial sums at part_off]; frames at clip
+  // edges (padding) or in unaligned clips are first staged here, span floats for FPW frames
+  int32_t span, direct, wave_floats, part_off;
   // LDS carve of the shared tables, in floats
-  int32_t off_win, off_tw1, off_tw2, off_mela, off_melbase, off_quadpos, off_boff, off_gw, off_wave;
-  int32_t mel_sets, mel_u, mel_maxpos, n_quads;
+  int32_t off_win, off_tw1, off_tw2, off_mela, off_melbase, off_quadpos, off_boff, off_gw, off_aff, off_zero, off_wave;
+  int32_t mel_sets, mel_u, mel_maxpos, n_quads, out_vec;
   unsigned long long* stamps;  // diagnostic build only: [wave][8] cycle sums
   int32_t skip;  // diagnostic: bit k set = phase k of the streaming loop is not executed (timing ablations only)
   const float* window;
@@ -156,94 +156,91 @@ __device__ __forceinline__ void stage_span(const FrontParams& p, float* dst, int
   }
 }
 
-// Per-lane constants of the mel stage, computed once per kernel launch and kept in registers.
-// gather word of output 64*r + lane: bits 0-10 offset of its first partial sum, 11-15 number of partial sums,
-// 16-22 filter index, 23-24 frame (0..3).
-__device__ __forceinline__ int mel_gather_word(const FrontParams& p, const int32_t* quadpos, int o) {
-  o = min(o, 4 * p.n_mels - 1);
-  const int jj = o / p.n_mels, m = o - jj * p.n_mels;
-  const int info = quadpos[m >> 2];
-  return ((info & 0xffff) * kPartStride + jj * 4 + (m & 3)) | ((info >> 16) << 11) | (m << 16) | (jj << 23);
+// Gather word of output lane `ol` (0..127): lane 4*quad + frame sums the partial sums of its quad for its frame.
+// bits 0-15: float offset of the first partial sum in the partial-sum region, bits 16-20: number of positions.
+__device__ __forceinline__ int mel_gather_word(const FrontParams& p, const int32_t* quadpos, int ol) {
+  const int q = ol >> 2, jj = ol & 3;
+  if (q >= p.n_quads) return 0;
+  const int info = quadpos[q];
+  return ((info & 0xffff) * kPartStride + jj * 4) | ((info >> 16) << 16);
 }
 
 // Mel projection of 4 frames (power rows prow0 + j*PITCH, j = 0..3) on the matrix pipe, then log/affine, then the
 // store of the (up to 4) x n_mels outputs straight to global memory.
 // Lane 4*block + j feeds the power of frame j as the B operand and the weight of filter 4*quad + j as the
-// A operand of block `block`; after the last instruction it holds, in acc[set][i], the partial sum of filter
-// 4*quad + i for frame j over the bins of position (set, block).  Each set's operands are fetched with one
-// burst of LDS reads; the partial sums of a filter are combined through LDS (kPartStride floats apart).
-template <int UMAX>
+// A operand of block `block`; after the last instruction it holds, in acc[i], the partial sum of filter
+// 4*quad + i for frame j over the bins of position (set, block).  Operands are fetched two steps of 4 bins ahead of
+// the instructions that consume them; the weight table carries one all-zero step per set, so an odd step count
+// needs no branch.  The partial sums of a quad are combined through LDS by lane 4*quad + frame, which then holds
+// 4 consecutive filters of one frame: one 16-byte store per lane, 1 KB contiguous per wavefront.
 __device__ __forceinline__ void mel_mfma_4frames(const FrontParams& p, const int32_t* boffL, const int32_t* gwL,
-                                                 const float* prow0, const float* mela, float* part, float* dst,
-                                                 int nvalid, int lane) {
-  // per-lane constants come from LDS tables ([set][lane], [r][lane]) in the same burst as the first operands
-  asm volatile("" : "+v"(lane));  // keeps the table reads inside the streaming loop instead of pinning registers
+                                                 const float* affL, const float* zero4, const float* prow0,
+                                                 const float* mela, float* part, float* dst, int nvalid, int lane) {
+  asm volatile("" : "+v"(lane));  // keeps the per-lane table reads inside the streaming loop instead of pinning registers
   const int blk = lane >> 2, j = lane & 3;
-  int boff[kMaxMelSets], gw[8];
-  static_for<0, kMaxMelSets>([&](auto Sf) { boff[decltype(Sf)::value] = boffL[decltype(Sf)::value * 64 + lane]; });
-  static_for<0, 8>([&](auto Rf) {
-    constexpr int r = decltype(Rf)::value;
-    gw[r] = (64 * r < 4 * p.n_mels) ? gwL[r * 64 + lane] : 0;
-  });
-  v4 acc[kMaxMelSets];
-  static_for<0, kMaxMelSets>([&](auto Sf) {
-    constexpr int s = decltype(Sf)::value;
-    acc[s] = v4{0.0f, 0.0f, 0.0f, 0.0f};
-    if (s < p.mel_sets) {
-      const float* bp = prow0 + boff[s];
-      const float* ap = mela + ((size_t)s * p.mel_u * 64 + lane) * 4;
-      for (int u0 = 0; u0 < p.mel_u; u0 += UMAX) {
-        v4 a[UMAX], b[UMAX];
-        static_for<0, UMAX>([&](auto Uf) {
-          constexpr int k = decltype(Uf)::value;
-          const int u = min(u0 + k, p.mel_u - 1);
-          a[k] = ld4(ap + u * 256);
-          b[k] = ld4(bp + 4 * u);
-        });
-        static_for<0, UMAX>([&](auto Uf) {
-          constexpr int k = decltype(Uf)::value;
-          if (u0 + k < p.mel_u) {
-            acc[s] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[k].x, b[k].x, acc[s], 0, 0, 0);
-            acc[s] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[k].y, b[k].y, acc[s], 0, 0, 0);
-            acc[s] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[k].z, b[k].z, acc[s], 0, 0, 0);
-            acc[s] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[k].w, b[k].w, acc[s], 0, 0, 0);
-          }
-        });
-      }
+  const int U = p.mel_u;
+  for (int s = 0; s < p.mel_sets; ++s) {
+    const float* bp = prow0 + boffL[s * 64 + lane];
+    const float* ap = mela + ((size_t)s * (U + 1) * 64 + lane) * 4;
+    v4 acc = v4{0.0f, 0.0f, 0.0f, 0.0f};
+    v4 a0 = ld4(ap), b0 = ld4(bp);
+    v4 a1 = ld4(ap + 256 * min(1, U)), b1 = ld4(bp + 4 * min(1, U - 1));
+    for (int u = 0; u < U; u += 2) {
+      const v4 na0 = ld4(ap + 256 * min(u + 2, U)), nb0 = ld4(bp + 4 * min(u + 2, U - 1));
+      const v4 na1 = ld4(ap + 256 * min(u + 3, U)), nb1 = ld4(bp + 4 * min(u + 3, U - 1));
+      acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.x, b0.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.y, b0.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.z, b0.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.w, b0.w, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.x, b1.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.y, b1.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.z, b1.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.w, b1.w, acc, 0, 0, 0);
+      a0 = na0; b0 = nb0; a1 = na1; b1 = nb1;
     }
-  });
-  static_for<0, kMaxMelSets>([&](auto Sf) {
-    constexpr int s = decltype(Sf)::value;
-    if (s < p.mel_sets) {
-      st4(part + (s * 16 + blk) * kPartStride + j * 4, acc[s]);
-    }
-  });
+    st4(part + (s * 16 + blk) * kPartStride + j * 4, acc);
+  }
   wave_phase_fence();
-  const int n_out = SED_SKIP(p, 64) ? 0 : 4 * p.n_mels;
-  static_for<0, 8>([&](auto Rf) {
-    constexpr int r = decltype(Rf)::value;
-    if (64 * r < n_out) {
-      const int npos = (gw[r] >> 11) & 31, m = (gw[r] >> 16) & 127, jj = (gw[r] >> 23) & 3;
-      const float* pp = part + (gw[r] & 0x7ff);
-      float sum = 0.0f;
-      for (int i0 = 0; i0 < npos; i0 += 8) {
-        float v[8];
-        static_for<0, 8>([&](auto If) { v[decltype(If)::value] = pp[(i0 + decltype(If)::value) * kPartStride]; });
-        static_for<0, 8>([&](auto If) { sum += (i0 + decltype(If)::value < npos) ? v[decltype(If)::value] : 0.0f; });
-      }
-      float val = log_epilogue(sum, p.log_kind, p.amin, p.db_offset, p.ln_offset);
-      if (p.affine) val = __builtin_fmaf(val, p.aff_scale[m], p.aff_shift[m]);
-      const int o = 64 * r + lane;
-      if (o < n_out && jj < nvalid) dst[o] = val;
+  if (SED_SKIP(p, 64)) return;
+  for (int r = 0; 16 * r < p.n_quads; ++r) {
+    const int g = gwL[r * 64 + lane];
+    const int npos = g >> 16;
+    const float* first = part + (g & 0xffff);
+    v4 sum = v4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int i0 = 0; i0 < p.mel_maxpos; i0 += 4) {
+      v4 v[4];
+      static_for<0, 4>([&](auto If) {
+        constexpr int i = decltype(If)::value;
+        v[i] = ld4((i0 + i < npos) ? first + (i0 + i) * kPartStride : zero4);
+      });
+      sum += (v[0] + v[1]) + (v[2] + v[3]);
     }
-  });
+    v4 val;
+    val.x = log_epilogue(sum.x, p.log_kind, p.amin, p.db_offset, p.ln_offset);
+    val.y = log_epilogue(sum.y, p.log_kind, p.amin, p.db_offset, p.ln_offset);
+    val.z = log_epilogue(sum.z, p.log_kind, p.amin, p.db_offset, p.ln_offset);
+    val.w = log_epilogue(sum.w, p.log_kind, p.amin, p.db_offset, p.ln_offset);
+    const int m0 = 4 * (16 * r + blk);  // first filter of this lane's quad; j is its frame
+    if (p.affine) val = __builtin_elementwise_fma(val, ld4(affL + m0), ld4(affL + 128 + m0));
+    if (j < nvalid && m0 < p.n_mels) {
+      float* o = dst + j * p.n_mels + m0;
+      if (p.out_vec) {
+        st4(o, val);
+      } else {
+        o[0] = val.x;
+        if (m0 + 1 < p.n_mels) o[1] = val.y;
+        if (m0 + 2 < p.n_mels) o[2] = val.z;
+        if (m0 + 3 < p.n_mels) o[3] = val.w;
+      }
+    }
+  }
   wave_phase_fence();
 }
 
 template <class G, bool MAG, bool SPEC_OUT>
 __global__ void __launch_bounds__(G::WAVES * 64, G::WAVES / 4) stft_mel_kernel(const FrontParams p) {
   extern __shared__ __align__(16) float smem[];
-  constexpr int NT = G::WAVES * 64;
+  const int NT = blockDim.x;  // up to G::WAVES wavefronts; the host launches fewer when LDS is short
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: chunk bookkeeping stays scalar
   const int lane = tid & 63;
@@ -257,13 +254,21 @@ __global__ void __launch_bounds__(G::WAVES * 64, G::WAVES / 4) stft_mel_kernel(c
   int32_t* quadposL = (int32_t*)(smem + p.off_quadpos);
   int32_t* boffL = (int32_t*)(smem + p.off_boff);
   int32_t* gwL = (int32_t*)(smem + p.off_gw);
+  float* affL = smem + p.off_aff;
+  float* zeroL = smem + p.off_zero;
   float* X = smem + p.off_wave + wave * p.wave_floats;
 
   for (int i = tid; i < G::NFFT; i += NT) winL[i] = p.window[i];
   for (int i = tid; i < G::R1 * G::R2; i += NT) tw1L[i] = p.tw1[i];
   for (int i = tid; i < G::SLOTS * G::LPF; i += NT) tw2L[i] = p.tw2[i];
   if constexpr (!SPEC_OUT) {
-    for (int i = tid; i < p.mel_sets * p.mel_u * 256; i += NT) melaL[i] = p.mela[i];
+    for (int i = tid; i < p.mel_sets * (p.mel_u + 1) * 256; i += NT) melaL[i] = p.mela[i];
+    if (p.affine)
+      for (int i = tid; i < 256; i += NT) {
+        const int m = i & 127;
+        affL[i] = m < p.n_mels ? (i < 128 ? p.aff_scale[m] : p.aff_shift[m]) : 0.0f;
+      }
+    if (tid < 4) zeroL[tid] = 0.0f;
     for (int i = tid; i < p.mel_sets * 16; i += NT) melbaseL[i] = p.melbase[i];
     for (int i = tid; i < p.n_quads; i += NT) quadposL[i] = p.quadpos[i];
   }
@@ -273,13 +278,13 @@ __global__ void __launch_bounds__(G::WAVES * 64, G::WAVES / 4) stft_mel_kernel(c
       const int s = i >> 6, ln = i & 63;
       boffL[i] = (s < p.mel_sets) ? (ln & 3) * G::PP + melbaseL[s * 16 + (ln >> 2)] : 0;
     }
-    for (int i = tid; i < 8 * 64; i += NT) gwL[i] = mel_gather_word(p, quadposL, i);
+    for (int i = tid; i < 2 * 64; i += NT) gwL[i] = mel_gather_word(p, quadposL, i);
     __syncthreads();
   }
 
   SED_STAMP_DECL
-  const int n_waves = gridDim.x * G::WAVES;
-  for (int chunk = blockIdx.x * G::WAVES + wave; chunk < p.total_chunks; chunk += n_waves) {
+  const int wg_waves = NT >> 6, n_waves = gridDim.x * wg_waves;
+  for (int chunk = blockIdx.x * wg_waves + wave; chunk < p.total_chunks; chunk += n_waves) {
     const int b = chunk / p.chunks_per_clip;
     const int f_begin = (chunk - b * p.chunks_per_clip) * p.chunk_frames;
     const int f_end = min(p.T, f_begin + p.chunk_frames);
@@ -322,10 +327,10 @@ __global__ void __launch_bounds__(G::WAVES * 64, G::WAVES / 4) stft_mel_kernel(c
         for (int f = 0; f < nvalid; ++f)
           for (int k = lane; k < G::NBINS; k += 64) dst[(int64_t)f * G::NBINS + k] = X[f * G::PP + k];
       } else {
-        float* part = X;  // the partial sums overlay the first 4 power rows, which the MFMAs have consumed by then
         float* dst = p.out + (int64_t)b * p.out_stride_b + (int64_t)f0 * p.n_mels;
         for (int g = 0; g < G::FPW / 4; ++g)
-          mel_mfma_4frames<8>(p, boffL, gwL, X + 4 * g * G::PP, melaL, part, dst + 4 * g * p.n_mels, nvalid - 4 * g, lane);
+          mel_mfma_4frames(p, boffL, gwL, affL, zeroL, X + 4 * g * G::PP, melaL, X + p.part_off, dst + 4 * g * p.n_mels,
+                           nvalid - 4 * g, lane);
         SED_STAMP(5)
       }
       wave_phase_fence();
@@ -334,7 +339,7 @@ __global__ void __launch_bounds__(G::WAVES * 64, G::WAVES / 4) stft_mel_kernel(c
   }
 #ifdef SED_STAMPS
   if (lane == 0 && p.stamps)
-    for (int k = 0; k < 8; ++k) p.stamps[(size_t)(blockIdx.x * G::WAVES + wave) * 8 + k] = st_acc[k];
+    for (int k = 0; k < 8; ++k) p.stamps[(size_t)(blockIdx.x * wg_waves + wave) * 8 + k] = st_acc[k];
 #endif
 }
 
@@ -625,28 +630,33 @@ static int launch_front(const sed_plan* pl, FrontParams p, int64_t B, hipStream_
   // per-wave LDS region
   p.span = (G::FPW - 1) * p.hop + G::NFFT;
   p.direct = p.vec_ok;
-  const int part_floats = SPEC_OUT ? 0 : (p.mel_sets * 16 + 8) * kPartStride;  // partial sums + slack for the fixed-size gather
-  const int xwf = round4(std::max(std::max(G::FPW * G::XFR, G::FPW * G::PP), part_floats));
-  p.wave_floats = round64(std::max(p.span, xwf));
+  p.part_off = G::FPW * G::PP;
+  const int part_floats = SPEC_OUT ? 0 : p.mel_sets * 16 * kPartStride;
+  p.wave_floats = round64(std::max(std::max(p.span, G::FPW * G::XFR), p.part_off + part_floats));
   // shared tables
   int off = 0;
   p.off_win = off; off += G::NFFT;
   p.off_tw1 = off; off += 2 * G::R1 * G::R2;
   p.off_tw2 = off; off += round4(2 * G::SLOTS * G::LPF);
-  p.off_mela = off; off += SPEC_OUT ? 0 : p.mel_sets * p.mel_u * 256;
+  p.off_mela = off; off += SPEC_OUT ? 0 : p.mel_sets * (p.mel_u + 1) * 256;
   p.off_melbase = off; off += SPEC_OUT ? 0 : round4(p.mel_sets * 16);
   p.off_quadpos = off; off += SPEC_OUT ? 0 : round4(p.n_quads);
   p.off_boff = off; off += SPEC_OUT ? 0 : kMaxMelSets * 64;
-  p.off_gw = off; off += SPEC_OUT ? 0 : 8 * 64;
+  p.off_gw = off; off += SPEC_OUT ? 0 : 2 * 64;
+  p.off_aff = off; off += (SPEC_OUT || !p.affine) ? 0 : 256;
+  p.off_zero = off; off += 4;
   p.off_wave = round64(off);
-  const size_t lds_bytes = (size_t)(p.off_wave + G::WAVES * p.wave_floats) * sizeof(float);
+  // as many wavefronts per workgroup as the geometry allows and LDS holds
+  int waves = G::WAVES;
+  while (waves > 1 && (size_t)(p.off_wave + waves * p.wave_floats) * sizeof(float) > 160 * 1024) --waves;
+  const size_t lds_bytes = (size_t)(p.off_wave + waves * p.wave_floats) * sizeof(float);
   if (lds_bytes > 160 * 1024) return SED_ERR_BAD_ARG;
   auto kern = stft_mel_kernel<G, MAG, SPEC_OUT>;
   SED_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds_bytes));
   // chunks: runs of consecutive frames of one clip, one wavefront each
   const int per_cu = std::max(1, std::min(2, (int)((160 * 1024) / lds_bytes)));
-  const int64_t max_waves = (int64_t)pl->num_cus * per_cu * G::WAVES;
+  const int64_t max_waves = (int64_t)pl->num_cus * per_cu * waves;
   const int64_t total_frames = B * (int64_t)p.T;
   int64_t cf = (total_frames + max_waves - 1) / max_waves;
   cf = std::max<int64_t>(cf, 4 * G::FPW);
@@ -659,13 +669,13 @@ static int launch_front(const sed_plan* pl, FrontParams p, int64_t B, hipStream_
   const int64_t total_chunks = (int64_t)p.chunks_per_clip * B;
   if (total_chunks > INT32_MAX / 2) return SED_ERR_BAD_ARG;
   p.total_chunks = (int32_t)total_chunks;
-  const int blocks = (int)std::min<int64_t>((total_chunks + G::WAVES - 1) / G::WAVES, (int64_t)pl->num_cus * per_cu);
+  const int blocks = (int)std::min<int64_t>((total_chunks + waves - 1) / waves, (int64_t)pl->num_cus * per_cu);
 #ifdef SED_STAMPS
   static unsigned long long* d_stamps = nullptr;
-  const size_t n_st = (size_t)blocks * G::WAVES * 8;
+  const size_t n_st = (size_t)blocks * waves * 8;
   if (!d_stamps) (void)hipMalloc((void**)&d_stamps, 4096 * 8 * 8 * sizeof(unsigned long long));
   p.stamps = d_stamps;
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(G::WAVES * 64), lds_bytes, stream, p);
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(waves * 64), lds_bytes, stream, p);
   static int calls = 0;
   if (++calls == 20) {
     (void)hipDeviceSynchronize();
@@ -680,7 +690,7 @@ static int launch_front(const sed_plan* pl, FrontParams p, int64_t B, hipStream_
   }
   return hip_status(hipGetLastError());
 #else
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(G::WAVES * 64), lds_bytes, stream, p);
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(waves * 64), lds_bytes, stream, p);
   return hip_status(hipGetLastError());
 #endif
 }
@@ -732,6 +742,7 @@ static int front_forward(const sed_plan* pl, const void* pcm, int64_t B, int64_t
   const size_t esz = c.pcm_kind == SED_PCM_I16 ? 2 : 4;
   const size_t need = c.pcm_kind == SED_PCM_I16 ? 8 : 16;
   p.vec_ok = ((uintptr_t)pcm % need == 0) && ((pcm_stride * esz) % need == 0) ? 1 : 0;
+  p.out_vec = (c.n_mels % 4 == 0) && ((uintptr_t)out % 16 == 0) && (out_stride_b % 4 == 0) ? 1 : 0;
   static const int debug_skip = getenv("SED_DEBUG_SKIP") ? atoi(getenv("SED_DEBUG_SKIP")) : 0;
   p.skip = debug_skip;
   hipStream_t s = (hipStream_t)stream;
