@@ -174,11 +174,10 @@ struct SrcI16 {
   }
 };
 
-// Stage 1 for lane l of a frame: load + window, R1-point FFT(s), inter-stage twiddle.
-// src: the frame's NFFT samples; win: NFFT window values (already holding the factor 1/2);
-// tw1[k1*R2 + n2] = W_NC^(n2*k1).
+// Stage 1 for lane l of a frame, first half: load + window into bit-reversed order.
+// src: the frame's NFFT samples; win: NFFT window values (already holding the factor 1/2).
 template <class G, class Src>
-SED_HD void lane_stage1(LaneState<G>& st, const Src src, const float* win, const cplx* tw1, int l) {
+SED_HD void lane_load_window(LaneState<G>& st, const Src src, const float* win, int l) {
   constexpr int LOG1 = ilog2(G::R1);
   static_for<0, G::R1>([&](auto N1) {
     constexpr int n1 = decltype(N1)::value;
@@ -191,6 +190,11 @@ SED_HD void lane_stage1(LaneState<G>& st, const Src src, const float* win, const
       st.y[1][pos] = pw.zw;
     }
   });
+}
+
+// Stage 1, second half: R1-point FFT(s) and the inter-stage twiddle; tw1[k1*R2 + n2] = W_NC^(n2*k1).
+template <class G>
+SED_HD void lane_fft1_twiddle(LaneState<G>& st, const cplx* tw1, int l) {
   static_for<0, G::A>([&](auto Af) {
     constexpr int a = decltype(Af)::value;
     fft_dit<G::R1>(st.y[a]);
@@ -200,6 +204,12 @@ SED_HD void lane_stage1(LaneState<G>& st, const Src src, const float* win, const
       st.y[a][k1] = cmul(st.y[a][k1], ld2(tw1 + k1 * G::R2 + n2));
     });
   });
+}
+
+template <class G, class Src>
+SED_HD void lane_stage1(LaneState<G>& st, const Src src, const float* win, const cplx* tw1, int l) {
+  lane_load_window<G>(st, src, win, l);
+  lane_fft1_twiddle<G>(st, tw1, l);
 }
 
 // Exchange phase PH (0: k1 in [0, R1/2), 1: k1 in [R1/2, R1)): lane l writes row n2 of the frame's region.

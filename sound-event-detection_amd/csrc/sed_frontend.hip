@@ -49,7 +49,7 @@ struct FrontParams {
   int32_t chunk_frames, chunks_per_clip, total_chunks;
   // per-wave LDS region, in floats: [exchange rows | power rows, then mel partial sums at part_off]; frames at clip
   // edges (padding) or in unaligned clips are first staged here, span floats for FPW frames
-  int32_t span, direct, wave_floats, part_off;
+  int32_t span, span_blocks, dma, wave_floats, part_off;
   // LDS carve of the shared tables, in floats
   int32_t off_win, off_tw1, off_tw2, off_mela, off_melbase, off_quadpos, off_boff, off_gw, off_aff, off_zero, off_wave;
   int32_t mel_sets, mel_u, mel_maxpos, n_quads, out_vec;
@@ -179,7 +179,7 @@ __device__ __forceinline__ void mel_mfma_4frames(const FrontParams& p, const int
   asm volatile("" : "+v"(lane));  // keeps the per-lane table reads inside the streaming loop instead of pinning registers
   const int blk = lane >> 2, j = lane & 3;
   const int U = p.mel_u;
-  for (int s = 0; s < p.mel_sets; ++s) {
+  for (int s = 0; s < (SED_SKIP(p, 32) ? 0 : p.mel_sets); ++s) {
     const float* bp = prow0 + boffL[s * 64 + lane];
     const float* ap = mela + ((size_t)s * (U + 1) * 64 + lane) * 4;
     v4 acc = v4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -293,15 +293,22 @@ __global__ void __launch_bounds__(G::WAVES * 64, G::WAVES / 4) stft_mel_kernel(c
       LaneState<G> st;
       // Interior frames of aligned clips are read straight from global memory: each lane fetches its own samples
       // (8 or 16 B per load, R1 independent loads in flight), the overlap between frames is served by L1/L2.
-      if (p.direct && s0 >= 0 && s0 + p.span <= p.L) {
-        const int64_t first = (int64_t)b * p.pcm_stride + s0 + fi * p.hop;
-        if (p.pcm_kind == SED_PCM_F32) lane_stage1<G>(st, SrcF32{(const float*)p.pcm + first}, winL, tw1L, l);
-        else lane_stage1<G>(st, SrcI16{(const short*)p.pcm + first, p.pcm_div}, winL, tw1L, l);
+      if (p.dma && s0 >= 0 && s0 + p.span <= p.L) {
+        // Interior frames of 16-byte-aligned fp32 clips: the span of the FPW frames goes from global memory straight
+        // to LDS (no registers in between), 16 bytes per lane and 1 KB per instruction, every sample fetched once.
+        // The last block re-reads the span's final bytes (clamped source) and lands past the span.
+        const float* src = (const float*)p.pcm + (int64_t)b * p.pcm_stride + s0;
+        if (!SED_SKIP(p, 1))
+          for (int k = 0; k < p.span_blocks; ++k)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + min(256 * k + 4 * lane, p.span - 4)),
+                                             (__attribute__((address_space(3))) void*)(X + 256 * k), 16, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       } else {
         stage_span(p, X, b, s0, p.span, lane);
-        wave_phase_fence();
-        lane_stage1<G>(st, SrcF32{X + fi * p.hop}, winL, tw1L, l);
       }
+      wave_phase_fence();
+      lane_load_window<G>(st, SrcF32{X + fi * p.hop}, winL, l);
+      if (!SED_SKIP(p, 2)) lane_fft1_twiddle<G>(st, tw1L, l);
       wave_phase_fence();
       SED_STAMP(1)
       float* xfr = X + fi * G::XFR;
@@ -629,10 +636,10 @@ template <class G, bool MAG, bool SPEC_OUT>
 static int launch_front(const sed_plan* pl, FrontParams p, int64_t B, hipStream_t stream) {
   // per-wave LDS region
   p.span = (G::FPW - 1) * p.hop + G::NFFT;
-  p.direct = p.vec_ok;
+  p.span_blocks = (p.span + 255) / 256;
   p.part_off = G::FPW * G::PP;
   const int part_floats = SPEC_OUT ? 0 : p.mel_sets * 16 * kPartStride;
-  p.wave_floats = round64(std::max(std::max(p.span, G::FPW * G::XFR), p.part_off + part_floats));
+  p.wave_floats = round64(std::max(std::max(256 * p.span_blocks, G::FPW * G::XFR), p.part_off + part_floats));
   // shared tables
   int off = 0;
   p.off_win = off; off += G::NFFT;
@@ -742,6 +749,7 @@ static int front_forward(const sed_plan* pl, const void* pcm, int64_t B, int64_t
   const size_t esz = c.pcm_kind == SED_PCM_I16 ? 2 : 4;
   const size_t need = c.pcm_kind == SED_PCM_I16 ? 8 : 16;
   p.vec_ok = ((uintptr_t)pcm % need == 0) && ((pcm_stride * esz) % need == 0) ? 1 : 0;
+  p.dma = (c.pcm_kind == SED_PCM_F32) && ((uintptr_t)pcm % 16 == 0) && (pcm_stride % 4 == 0) ? 1 : 0;  // hop, n_fft/2: multiples of 4
   p.out_vec = (c.n_mels % 4 == 0) && ((uintptr_t)out % 16 == 0) && (out_stride_b % 4 == 0) ? 1 : 0;
   static const int debug_skip = getenv("SED_DEBUG_SKIP") ? atoi(getenv("SED_DEBUG_SKIP")) : 0;
   p.skip = debug_skip;
