@@ -24,6 +24,15 @@
 #define SED_HD inline
 #endif
 
+// Keeps the compiler's instruction scheduler from moving anything across this point (device code only).  Used to pin
+// batches of LDS reads ahead of the arithmetic that hides their latency: left alone, the scheduler sinks every table
+// read to just before its use and then waits for it, one LDS round trip per value.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SED_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define SED_SCHED_FENCE() ((void)0)
+#endif
+
 namespace sed {
 
 struct alignas(8) cplx {
@@ -174,42 +183,73 @@ struct SrcI16 {
   }
 };
 
-// Stage 1 for lane l of a frame, first half: load + window into bit-reversed order.
-// src: the frame's NFFT samples; win: NFFT window values (already holding the factor 1/2).
+// Stage 1 for lane l of a frame: load + window, R1-point FFT(s), inter-stage twiddle.
+// src: the frame's NFFT samples; win: NFFT window values (already holding the factor 1/2);
+// tw1[k1*R2 + n2] = W_NC^(n2*k1).
+// Issue order: all samples and the first half of the window, then (as the products of the first half are formed)
+// the second half of the window and the twiddles, so that every table value is in flight long before it is used.
 template <class G, class Src>
-SED_HD void lane_load_window(LaneState<G>& st, const Src src, const float* win, int l) {
-  constexpr int LOG1 = ilog2(G::R1);
-  static_for<0, G::R1>([&](auto N1) {
-    constexpr int n1 = decltype(N1)::value;
-    constexpr int pos = bitrev(n1, LOG1);
-    if constexpr (G::A == 1) {
-      st.y[0][pos] = src.load2(2 * G::R2 * n1 + 2 * l) * ld2(win + 2 * G::R2 * n1 + 2 * l);
-    } else {
+SED_HD void lane_stage1(LaneState<G>& st, const Src src, const float* win, const cplx* tw1, int l) {
+  constexpr int LOG1 = ilog2(G::R1), H = G::R1 / 2;
+  if constexpr (G::A == 1) {
+    constexpr int Q = G::R1 / 4;
+    v2 w[4][Q], ta[H], tb[H];
+    auto issue_window = [&](auto Qf) {
+      constexpr int q = decltype(Qf)::value;
+      static_for<0, Q>([&](auto N1) { w[q][decltype(N1)::value] = ld2(win + 2 * G::R2 * (Q * q + decltype(N1)::value) + 2 * l); });
+    };
+    auto apply_window = [&](auto Qf) {
+      constexpr int q = decltype(Qf)::value;
+      static_for<0, Q>([&](auto N1) { st.y[0][bitrev(Q * q + decltype(N1)::value, LOG1)] *= w[q][decltype(N1)::value]; });
+    };
+    static_for<0, G::R1>([&](auto N1) {
+      constexpr int n1 = decltype(N1)::value;
+      st.y[0][bitrev(n1, LOG1)] = src.load2(2 * G::R2 * n1 + 2 * l);
+    });
+    issue_window(std::integral_constant<int, 0>{});
+    issue_window(std::integral_constant<int, 1>{});
+    SED_SCHED_FENCE();
+    apply_window(std::integral_constant<int, 0>{});
+    issue_window(std::integral_constant<int, 2>{});
+    SED_SCHED_FENCE();
+    apply_window(std::integral_constant<int, 1>{});
+    issue_window(std::integral_constant<int, 3>{});
+    SED_SCHED_FENCE();
+    apply_window(std::integral_constant<int, 2>{});
+    static_for<1, H>([&](auto K1) { ta[decltype(K1)::value] = ld2(tw1 + decltype(K1)::value * G::R2 + l); });
+    SED_SCHED_FENCE();
+    apply_window(std::integral_constant<int, 3>{});
+    SED_SCHED_FENCE();
+    fft_dit<G::R1>(st.y[0]);
+    SED_SCHED_FENCE();
+    static_for<0, H>([&](auto K1) { tb[decltype(K1)::value] = ld2(tw1 + (H + decltype(K1)::value) * G::R2 + l); });
+    static_for<1, H>([&](auto K1) {
+      constexpr int k1 = decltype(K1)::value;
+      st.y[0][k1] = cmul(st.y[0][k1], ta[k1]);
+    });
+    SED_SCHED_FENCE();
+    static_for<0, H>([&](auto K1) {
+      constexpr int k1 = decltype(K1)::value;
+      st.y[0][H + k1] = cmul(st.y[0][H + k1], tb[k1]);
+    });
+  } else {
+    static_for<0, G::R1>([&](auto N1) {
+      constexpr int n1 = decltype(N1)::value;
+      constexpr int pos = bitrev(n1, LOG1);
       const v4 pw = src.load4(2 * G::R2 * n1 + 4 * l) * ld4(win + 2 * G::R2 * n1 + 4 * l);
       st.y[0][pos] = pw.xy;
       st.y[1][pos] = pw.zw;
-    }
-  });
-}
-
-// Stage 1, second half: R1-point FFT(s) and the inter-stage twiddle; tw1[k1*R2 + n2] = W_NC^(n2*k1).
-template <class G>
-SED_HD void lane_fft1_twiddle(LaneState<G>& st, const cplx* tw1, int l) {
-  static_for<0, G::A>([&](auto Af) {
-    constexpr int a = decltype(Af)::value;
-    fft_dit<G::R1>(st.y[a]);
-    const int n2 = G::A * l + a;
-    static_for<1, G::R1>([&](auto K1) {
-      constexpr int k1 = decltype(K1)::value;
-      st.y[a][k1] = cmul(st.y[a][k1], ld2(tw1 + k1 * G::R2 + n2));
     });
-  });
-}
-
-template <class G, class Src>
-SED_HD void lane_stage1(LaneState<G>& st, const Src src, const float* win, const cplx* tw1, int l) {
-  lane_load_window<G>(st, src, win, l);
-  lane_fft1_twiddle<G>(st, tw1, l);
+    static_for<0, G::A>([&](auto Af) {
+      constexpr int a = decltype(Af)::value;
+      fft_dit<G::R1>(st.y[a]);
+      const int n2 = G::A * l + a;
+      static_for<1, G::R1>([&](auto K1) {
+        constexpr int k1 = decltype(K1)::value;
+        st.y[a][k1] = cmul(st.y[a][k1], ld2(tw1 + k1 * G::R2 + n2));
+      });
+    });
+  }
 }
 
 // Exchange phase PH (0: k1 in [0, R1/2), 1: k1 in [R1/2, R1)): lane l writes row n2 of the frame's region.

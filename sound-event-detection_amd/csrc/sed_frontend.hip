@@ -49,7 +49,7 @@ struct FrontParams {
   int32_t chunk_frames, chunks_per_clip, total_chunks;
   // per-wave LDS region, in floats: [exchange rows | power rows, then mel partial sums at part_off]; frames at clip
   // edges (padding) or in unaligned clips are first staged here, span floats for FPW frames
-  int32_t span, span_blocks, dma, wave_floats, part_off;
+  int32_t span, span_blocks, dma, early, wave_floats, part_off;
   // LDS carve of the shared tables, in floats
   int32_t off_win, off_tw1, off_tw2, off_mela, off_melbase, off_quadpos, off_boff, off_gw, off_aff, off_zero, off_wave;
   int32_t mel_sets, mel_u, mel_maxpos, n_quads, out_vec;
@@ -81,12 +81,13 @@ __device__ __forceinline__ unsigned long long sed_stamp() {
 #define SED_STAMP(k)
 #endif
 
-// Orders LDS accesses of different lanes of ONE wavefront (the hardware executes a wave's LDS operations in
-// order; this only stops the compiler from moving them across the phase boundary).
+// Orders LDS accesses of different lanes of ONE wavefront.  The hardware executes a wavefront's LDS operations in
+// the order they were issued, so no wait is needed: this only stops the compiler from moving memory operations
+// across the phase boundary (a fence instruction would make it wait for every outstanding LDS access).
 __device__ __forceinline__ void wave_phase_fence() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  asm volatile("" ::: "memory");
   __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  asm volatile("" ::: "memory");
 }
 
 // log2 on the transcendental unit (v_log_f32, about 1 ulp of the log2 value), scaled to dB or nepers: the
@@ -156,6 +157,16 @@ __device__ __forceinline__ void stage_span(const FrontParams& p, float* dst, int
   }
 }
 
+// Interior spans of 16-byte-aligned fp32 clips go from global memory straight to LDS (no registers in between),
+// 16 bytes per lane and 1 KB per instruction, every sample fetched once per group of frames.  The last block
+// re-reads the span's final bytes (clamped source) and lands past the span.  Completion: vmcnt.
+__device__ __forceinline__ void stage_span_dma(const FrontParams& p, float* dst, int64_t b, int64_t s0, int lane) {
+  const float* src = (const float*)p.pcm + b * p.pcm_stride + s0;
+  for (int k = 0; k < p.span_blocks; ++k)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + min(256 * k + 4 * lane, p.span - 4)),
+                                     (__attribute__((address_space(3))) void*)(dst + 256 * k), 16, 0, 0);
+}
+
 // Gather word of output lane `ol` (0..127): lane 4*quad + frame sums the partial sums of its quad for its frame.
 // bits 0-15: float offset of the first partial sum in the partial-sum region, bits 16-20: number of positions.
 __device__ __forceinline__ int mel_gather_word(const FrontParams& p, const int32_t* quadpos, int ol) {
@@ -165,17 +176,14 @@ __device__ __forceinline__ int mel_gather_word(const FrontParams& p, const int32
   return ((info & 0xffff) * kPartStride + jj * 4) | ((info >> 16) << 16);
 }
 
-// Mel projection of 4 frames (power rows prow0 + j*PITCH, j = 0..3) on the matrix pipe, then log/affine, then the
-// store of the (up to 4) x n_mels outputs straight to global memory.
+// Mel projection of 4 frames (power rows prow0 + j*PITCH, j = 0..3) on the matrix pipe.
 // Lane 4*block + j feeds the power of frame j as the B operand and the weight of filter 4*quad + j as the
 // A operand of block `block`; after the last instruction it holds, in acc[i], the partial sum of filter
 // 4*quad + i for frame j over the bins of position (set, block).  Operands are fetched two steps of 4 bins ahead of
 // the instructions that consume them; the weight table carries one all-zero step per set, so an odd step count
-// needs no branch.  The partial sums of a quad are combined through LDS by lane 4*quad + frame, which then holds
-// 4 consecutive filters of one frame: one 16-byte store per lane, 1 KB contiguous per wavefront.
-__device__ __forceinline__ void mel_mfma_4frames(const FrontParams& p, const int32_t* boffL, const int32_t* gwL,
-                                                 const float* affL, const float* zero4, const float* prow0,
-                                                 const float* mela, float* part, float* dst, int nvalid, int lane) {
+// needs no branch.  The partial sums go to LDS, kPartStride floats per position.
+__device__ __forceinline__ void mel_mfma_4frames(const FrontParams& p, const int32_t* boffL, const float* prow0,
+                                                 const float* mela, float* part, int lane) {
   asm volatile("" : "+v"(lane));  // keeps the per-lane table reads inside the streaming loop instead of pinning registers
   const int blk = lane >> 2, j = lane & 3;
   const int U = p.mel_u;
@@ -201,44 +209,54 @@ __device__ __forceinline__ void mel_mfma_4frames(const FrontParams& p, const int
     st4(part + (s * 16 + blk) * kPartStride + j * 4, acc);
   }
   wave_phase_fence();
-  if (SED_SKIP(p, 64)) return;
-  for (int r = 0; 16 * r < p.n_quads; ++r) {
-    const int g = gwL[r * 64 + lane];
-    const int npos = g >> 16;
-    const float* first = part + (g & 0xffff);
-    v4 sum = v4{0.0f, 0.0f, 0.0f, 0.0f};
-    for (int i0 = 0; i0 < p.mel_maxpos; i0 += 4) {
-      v4 v[4];
-      static_for<0, 4>([&](auto If) {
-        constexpr int i = decltype(If)::value;
-        v[i] = ld4((i0 + i < npos) ? first + (i0 + i) * kPartStride : zero4);
-      });
-      sum += (v[0] + v[1]) + (v[2] + v[3]);
-    }
-    v4 val;
-    val.x = log_epilogue(sum.x, p.log_kind, p.amin, p.db_offset, p.ln_offset);
-    val.y = log_epilogue(sum.y, p.log_kind, p.amin, p.db_offset, p.ln_offset);
-    val.z = log_epilogue(sum.z, p.log_kind, p.amin, p.db_offset, p.ln_offset);
-    val.w = log_epilogue(sum.w, p.log_kind, p.amin, p.db_offset, p.ln_offset);
-    const int m0 = 4 * (16 * r + blk);  // first filter of this lane's quad; j is its frame
-    if (p.affine) val = __builtin_elementwise_fma(val, ld4(affL + m0), ld4(affL + 128 + m0));
-    if (j < nvalid && m0 < p.n_mels) {
-      float* o = dst + j * p.n_mels + m0;
-      if (p.out_vec) {
-        st4(o, val);
-      } else {
-        o[0] = val.x;
-        if (m0 + 1 < p.n_mels) o[1] = val.y;
-        if (m0 + 2 < p.n_mels) o[2] = val.z;
-        if (m0 + 3 < p.n_mels) o[3] = val.w;
-      }
+}
+
+// Round r of the gather: lane 4*q + j sums the partial sums of quad 16 r + q for frame j, takes the log and applies
+// the optional affine.  It then holds 4 consecutive filters of one frame.
+__device__ __forceinline__ v4 mel_gather_log(const FrontParams& p, const int32_t* gwL, const float* affL,
+                                             const float* zero4, const float* part, int r, int lane) {
+  asm volatile("" : "+v"(lane));
+  const int g = gwL[r * 64 + lane];
+  const int npos = g >> 16;
+  const float* first = part + (g & 0xffff);
+  v4 sum = v4{0.0f, 0.0f, 0.0f, 0.0f};
+  for (int i0 = 0; i0 < p.mel_maxpos; i0 += 4) {
+    v4 v[4];
+    static_for<0, 4>([&](auto If) {
+      constexpr int i = decltype(If)::value;
+      v[i] = ld4((i0 + i < npos) ? first + (i0 + i) * kPartStride : zero4);
+    });
+    sum += (v[0] + v[1]) + (v[2] + v[3]);
+  }
+  v4 val;
+  val.x = log_epilogue(sum.x, p.log_kind, p.amin, p.db_offset, p.ln_offset);
+  val.y = log_epilogue(sum.y, p.log_kind, p.amin, p.db_offset, p.ln_offset);
+  val.z = log_epilogue(sum.z, p.log_kind, p.amin, p.db_offset, p.ln_offset);
+  val.w = log_epilogue(sum.w, p.log_kind, p.amin, p.db_offset, p.ln_offset);
+  const int m0 = 4 * (16 * r + (lane >> 2));
+  if (p.affine) val = __builtin_elementwise_fma(val, ld4(affL + m0), ld4(affL + 128 + m0));
+  return val;
+}
+
+// Store of one gather round: 16 bytes per lane, 1 KB contiguous per wavefront (frames are n_mels floats apart).
+__device__ __forceinline__ void mel_store(const FrontParams& p, float* dst, v4 val, int r, int nvalid, int lane) {
+  const int j = lane & 3, m0 = 4 * (16 * r + (lane >> 2));
+  if (j < nvalid && m0 < p.n_mels) {
+    float* o = dst + j * p.n_mels + m0;
+    if (p.out_vec) {
+      st4(o, val);
+    } else {
+      o[0] = val.x;
+      if (m0 + 1 < p.n_mels) o[1] = val.y;
+      if (m0 + 2 < p.n_mels) o[2] = val.z;
+      if (m0 + 3 < p.n_mels) o[3] = val.w;
     }
   }
-  wave_phase_fence();
 }
 
 template <class G, bool MAG, bool SPEC_OUT>
-__global__ void __launch_bounds__(G::WAVES * 64, G::WAVES / 4) stft_mel_kernel(const FrontParams p) {
+__global__ void __launch_bounds__(G::WAVES * 64) __attribute__((amdgpu_waves_per_eu(G::WAVES / 4, G::WAVES / 4)))
+stft_mel_kernel(const FrontParams p) {
   extern __shared__ __align__(16) float smem[];
   const int NT = blockDim.x;  // up to G::WAVES wavefronts; the host launches fewer when LDS is short
   const int tid = threadIdx.x;
@@ -288,27 +306,38 @@ __global__ void __launch_bounds__(G::WAVES * 64, G::WAVES / 4) stft_mel_kernel(c
     const int b = chunk / p.chunks_per_clip;
     const int f_begin = (chunk - b * p.chunks_per_clip) * p.chunk_frames;
     const int f_end = min(p.T, f_begin + p.chunk_frames);
+    // Streaming state of the chunk.
+    //  staged : the span of the group about to be processed is already on its way into X (issued by the previous
+    //           iteration as soon as its power rows were consumed, so most of the fetch latency is hidden)
+    //  held   : log-mel values of the previous group, stored one iteration late: vmcnt counts loads and stores in
+    //           order, and a store issued just before the wait for the span would put its own latency on the path
+    constexpr int kGroups = G::FPW / 4;
+    bool staged = false, held = false;
+    v4 hval[kGroups][2];
+    float* hdst = nullptr;
+    int hvalid = 0;
     for (int f0 = f_begin; f0 < f_end; f0 += G::FPW) {
       const int64_t s0 = (int64_t)f0 * p.hop - p.pad_left;
       LaneState<G> st;
-      // Interior frames of aligned clips are read straight from global memory: each lane fetches its own samples
-      // (8 or 16 B per load, R1 independent loads in flight), the overlap between frames is served by L1/L2.
-      if (p.dma && s0 >= 0 && s0 + p.span <= p.L) {
-        // Interior frames of 16-byte-aligned fp32 clips: the span of the FPW frames goes from global memory straight
-        // to LDS (no registers in between), 16 bytes per lane and 1 KB per instruction, every sample fetched once.
-        // The last block re-reads the span's final bytes (clamped source) and lands past the span.
-        const float* src = (const float*)p.pcm + (int64_t)b * p.pcm_stride + s0;
-        if (!SED_SKIP(p, 1))
-          for (int k = 0; k < p.span_blocks; ++k)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + min(256 * k + 4 * lane, p.span - 4)),
-                                             (__attribute__((address_space(3))) void*)(X + 256 * k), 16, 0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      } else {
-        stage_span(p, X, b, s0, p.span, lane);
+      if (!staged) {
+        if (p.dma && s0 >= 0 && s0 + p.span <= p.L) {
+          if (!SED_SKIP(p, 1)) stage_span_dma(p, X, b, s0, lane);
+        } else {
+          stage_span(p, X, b, s0, p.span, lane);
+        }
       }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       wave_phase_fence();
-      lane_load_window<G>(st, SrcF32{X + fi * p.hop}, winL, l);
-      if (!SED_SKIP(p, 2)) lane_fft1_twiddle<G>(st, tw1L, l);
+      if constexpr (!SPEC_OUT) {
+        if (held) {
+          static_for<0, kGroups>([&](auto Gf) {
+            constexpr int g = decltype(Gf)::value;
+            mel_store(p, hdst + 4 * g * p.n_mels, hval[g][0], 0, hvalid - 4 * g, lane);
+            if (p.n_quads > 16) mel_store(p, hdst + 4 * g * p.n_mels, hval[g][1], 1, hvalid - 4 * g, lane);
+          });
+        }
+      }
+      lane_stage1<G>(st, SrcF32{X + fi * p.hop}, winL, tw1L, l);
       wave_phase_fence();
       SED_STAMP(1)
       float* xfr = X + fi * G::XFR;
@@ -329,19 +358,46 @@ __global__ void __launch_bounds__(G::WAVES * 64, G::WAVES / 4) stft_mel_kernel(c
       wave_phase_fence();
       SED_STAMP(4)
       const int nvalid = min(G::FPW, f_end - f0);
+      staged = false;
       if constexpr (SPEC_OUT) {
         float* dst = p.out + (int64_t)b * p.out_stride_b + (int64_t)f0 * G::NBINS;
         for (int f = 0; f < nvalid; ++f)
           for (int k = lane; k < G::NBINS; k += 64) dst[(int64_t)f * G::NBINS + k] = X[f * G::PP + k];
       } else {
-        float* dst = p.out + (int64_t)b * p.out_stride_b + (int64_t)f0 * p.n_mels;
-        for (int g = 0; g < G::FPW / 4; ++g)
-          mel_mfma_4frames(p, boffL, gwL, affL, zeroL, X + 4 * g * G::PP, melaL, X + p.part_off, dst + 4 * g * p.n_mels,
-                           nvalid - 4 * g, lane);
+        float* part = X + p.part_off;
+        static_for<0, kGroups>([&](auto Gf) {
+          constexpr int g = decltype(Gf)::value;
+          mel_mfma_4frames(p, boffL, X + 4 * g * G::PP, melaL, part, lane);
+          if constexpr (g == kGroups - 1) {
+            // the power rows are consumed: the next group's span may land on them while the gather runs
+            const int64_t s1 = s0 + (int64_t)G::FPW * p.hop;
+            if (p.early && f0 + G::FPW < f_end && s1 >= 0 && s1 + p.span <= p.L && !SED_SKIP(p, 1)) {
+              stage_span_dma(p, X, b, s1, lane);
+              staged = true;
+            }
+          }
+          if (!SED_SKIP(p, 64)) {
+            hval[g][0] = mel_gather_log(p, gwL, affL, zeroL, part, 0, lane);
+            if (p.n_quads > 16) hval[g][1] = mel_gather_log(p, gwL, affL, zeroL, part, 1, lane);
+          }
+          wave_phase_fence();
+        });
+        held = !SED_SKIP(p, 64);
+        hdst = p.out + (int64_t)b * p.out_stride_b + (int64_t)f0 * p.n_mels;
+        hvalid = nvalid;
         SED_STAMP(5)
       }
       wave_phase_fence();
       SED_STAMP(6)
+    }
+    if constexpr (!SPEC_OUT) {
+      if (held) {
+        static_for<0, kGroups>([&](auto Gf) {
+          constexpr int g = decltype(Gf)::value;
+          mel_store(p, hdst + 4 * g * p.n_mels, hval[g][0], 0, hvalid - 4 * g, lane);
+          if (p.n_quads > 16) mel_store(p, hdst + 4 * g * p.n_mels, hval[g][1], 1, hvalid - 4 * g, lane);
+        });
+      }
     }
   }
 #ifdef SED_STAMPS
@@ -638,6 +694,7 @@ static int launch_front(const sed_plan* pl, FrontParams p, int64_t B, hipStream_
   p.span = (G::FPW - 1) * p.hop + G::NFFT;
   p.span_blocks = (p.span + 255) / 256;
   p.part_off = G::FPW * G::PP;
+  p.early = p.dma && !SPEC_OUT && 256 * p.span_blocks <= p.part_off;  // the span may land while the partial sums are in use
   const int part_floats = SPEC_OUT ? 0 : p.mel_sets * 16 * kPartStride;
   p.wave_floats = round64(std::max(std::max(256 * p.span_blocks, G::FPW * G::XFR), p.part_off + part_floats));
   // shared tables
@@ -655,6 +712,8 @@ static int launch_front(const sed_plan* pl, FrontParams p, int64_t B, hipStream_
   p.off_wave = round64(off);
   // as many wavefronts per workgroup as the geometry allows and LDS holds
   int waves = G::WAVES;
+  static const int debug_waves = getenv("SED_DEBUG_WAVES") ? atoi(getenv("SED_DEBUG_WAVES")) : 0;
+  if (debug_waves > 0) waves = std::min(waves, debug_waves);
   while (waves > 1 && (size_t)(p.off_wave + waves * p.wave_floats) * sizeof(float) > 160 * 1024) --waves;
   const size_t lds_bytes = (size_t)(p.off_wave + waves * p.wave_floats) * sizeof(float);
   if (lds_bytes > 160 * 1024) return SED_ERR_BAD_ARG;
