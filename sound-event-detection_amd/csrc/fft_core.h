@@ -144,10 +144,36 @@ struct Geo {
   static constexpr int XFR = R2 * RP + 32;  // exchange floats per frame
   static constexpr int PP = NC + 16;        // power-row pitch in floats (16 mod 64: the 4 frames of a wave tile the banks)
   static constexpr int SLOTS = R2 + 1;      // split slots per lane (one of them stores from lane 0 only)
+  // Lane-major table layouts: the values one lane reads are contiguous, so that it fetches two of them per 16-byte
+  // LDS read; row pitches are 4 * odd floats, which spreads the 16 lanes of a frame over all banks.
+  static constexpr int WROW = 2 * R1 + 4;                       // window row of lane l: (w[2(R2 n1 + l)], w[.. + 1]) for n1 = 0..R1-1
+  static constexpr int WIN_FLOATS = A == 1 ? LPF * WROW : NFFT; // (natural order when a lane already reads 16 bytes per n1)
+  static constexpr int TROW = 2 * R1 + 4;                       // inter-stage twiddle row of n2: W_NC^(n2 k1), k1 = 0..R1-1
+  static constexpr int TW1_FLOATS = A == 1 ? R2 * TROW : 2 * R1 * R2;
+  static constexpr int SROW = (2 * (SLOTS + 1) + 3) / 4 * 4;    // split twiddle row of lane l: slots 0..SLOTS-1 (+ padding)
+  static constexpr int TW2_FLOATS = LPF * SROW;
+  static_assert((WROW / 4) % 2 == 1 && (SROW / 4) % 2 == 1, "row pitches must be 4 * odd floats");
   static_assert(R1 == 2 * LPF, "two stage-2 FFTs per lane");
   static_assert(A == 1 || A == 2, "one or two stage-1 FFTs per lane");
   static_assert(R1 <= 32 && R2 <= 32, "twiddle literals cover N <= 32");
 };
+
+// Position (in floats) of natural-order table entries in the lane-major LDS tables.
+template <class G>
+SED_HD int win_slot(int i) {  // window sample i
+  if constexpr (G::A != 1) return i;
+  const int n1 = i / (2 * G::R2), rem = i % (2 * G::R2);
+  return (rem >> 1) * G::WROW + 2 * n1 + (rem & 1);
+}
+template <class G>
+SED_HD int tw1_slot(int k1, int n2) {  // W_NC^(n2 k1)
+  if constexpr (G::A != 1) return 2 * (k1 * G::R2 + n2);
+  return n2 * G::TROW + 2 * k1;
+}
+template <class G>
+SED_HD int tw2_slot(int t, int l) {  // split twiddle of slot t in lane l
+  return l * G::SROW + 2 * t;
+}
 
 template <class G>
 struct LaneState {
@@ -184,23 +210,29 @@ struct SrcI16 {
 };
 
 // Stage 1 for lane l of a frame: load + window, R1-point FFT(s), inter-stage twiddle.
-// src: the frame's NFFT samples; win: NFFT window values (already holding the factor 1/2);
-// tw1[k1*R2 + n2] = W_NC^(n2*k1).
+// src: the frame's NFFT samples; win: window (already holding the factor 1/2) at win_slot(); tw1: W_NC^(n2*k1) at
+// tw1_slot().
 // Issue order: all samples and the first half of the window, then (as the products of the first half are formed)
 // the second half of the window and the twiddles, so that every table value is in flight long before it is used.
 template <class G, class Src>
-SED_HD void lane_stage1(LaneState<G>& st, const Src src, const float* win, const cplx* tw1, int l) {
+SED_HD void lane_stage1(LaneState<G>& st, const Src src, const float* win, const float* tw1, int l) {
   constexpr int LOG1 = ilog2(G::R1), H = G::R1 / 2;
   if constexpr (G::A == 1) {
-    constexpr int Q = G::R1 / 4;
-    v2 w[4][Q], ta[H], tb[H];
+    constexpr int Q = G::R1 / 4;  // window values per quarter, fetched two at a time
+    const float* wrow = win + l * G::WROW;
+    const float* trow = tw1 + l * G::TROW;
+    v4 w[4][Q / 2], ta[H / 2], tb[H / 2];
     auto issue_window = [&](auto Qf) {
       constexpr int q = decltype(Qf)::value;
-      static_for<0, Q>([&](auto N1) { w[q][decltype(N1)::value] = ld2(win + 2 * G::R2 * (Q * q + decltype(N1)::value) + 2 * l); });
+      static_for<0, Q / 2>([&](auto Pf) { w[q][decltype(Pf)::value] = ld4(wrow + 2 * Q * q + 4 * decltype(Pf)::value); });
     };
     auto apply_window = [&](auto Qf) {
       constexpr int q = decltype(Qf)::value;
-      static_for<0, Q>([&](auto N1) { st.y[0][bitrev(Q * q + decltype(N1)::value, LOG1)] *= w[q][decltype(N1)::value]; });
+      static_for<0, Q / 2>([&](auto Pf) {
+        constexpr int i = decltype(Pf)::value, n1 = Q * q + 2 * i;
+        st.y[0][bitrev(n1, LOG1)] *= w[q][i].xy;
+        st.y[0][bitrev(n1 + 1, LOG1)] *= w[q][i].zw;
+      });
     };
     static_for<0, G::R1>([&](auto N1) {
       constexpr int n1 = decltype(N1)::value;
@@ -216,21 +248,23 @@ SED_HD void lane_stage1(LaneState<G>& st, const Src src, const float* win, const
     issue_window(std::integral_constant<int, 3>{});
     SED_SCHED_FENCE();
     apply_window(std::integral_constant<int, 2>{});
-    static_for<1, H>([&](auto K1) { ta[decltype(K1)::value] = ld2(tw1 + decltype(K1)::value * G::R2 + l); });
+    static_for<0, H / 2>([&](auto Pf) { ta[decltype(Pf)::value] = ld4(trow + 4 * decltype(Pf)::value); });
     SED_SCHED_FENCE();
     apply_window(std::integral_constant<int, 3>{});
     SED_SCHED_FENCE();
     fft_dit<G::R1>(st.y[0]);
     SED_SCHED_FENCE();
-    static_for<0, H>([&](auto K1) { tb[decltype(K1)::value] = ld2(tw1 + (H + decltype(K1)::value) * G::R2 + l); });
-    static_for<1, H>([&](auto K1) {
-      constexpr int k1 = decltype(K1)::value;
-      st.y[0][k1] = cmul(st.y[0][k1], ta[k1]);
+    static_for<0, H / 2>([&](auto Pf) { tb[decltype(Pf)::value] = ld4(trow + 2 * H + 4 * decltype(Pf)::value); });
+    static_for<0, H / 2>([&](auto Pf) {
+      constexpr int i = decltype(Pf)::value;
+      if constexpr (i > 0) st.y[0][2 * i] = cmul(st.y[0][2 * i], ta[i].xy);  // k1 = 0: W^0
+      st.y[0][2 * i + 1] = cmul(st.y[0][2 * i + 1], ta[i].zw);
     });
     SED_SCHED_FENCE();
-    static_for<0, H>([&](auto K1) {
-      constexpr int k1 = decltype(K1)::value;
-      st.y[0][H + k1] = cmul(st.y[0][H + k1], tb[k1]);
+    static_for<0, H / 2>([&](auto Pf) {
+      constexpr int i = decltype(Pf)::value;
+      st.y[0][H + 2 * i] = cmul(st.y[0][H + 2 * i], tb[i].xy);
+      st.y[0][H + 2 * i + 1] = cmul(st.y[0][H + 2 * i + 1], tb[i].zw);
     });
   } else {
     static_for<0, G::R1>([&](auto N1) {
@@ -240,14 +274,13 @@ SED_HD void lane_stage1(LaneState<G>& st, const Src src, const float* win, const
       st.y[0][pos] = pw.xy;
       st.y[1][pos] = pw.zw;
     });
-    static_for<0, G::A>([&](auto Af) {
-      constexpr int a = decltype(Af)::value;
-      fft_dit<G::R1>(st.y[a]);
-      const int n2 = G::A * l + a;
-      static_for<1, G::R1>([&](auto K1) {
-        constexpr int k1 = decltype(K1)::value;
-        st.y[a][k1] = cmul(st.y[a][k1], ld2(tw1 + k1 * G::R2 + n2));
-      });
+    fft_dit<G::R1>(st.y[0]);
+    fft_dit<G::R1>(st.y[1]);
+    static_for<1, G::R1>([&](auto K1) {  // n2 = 2l and 2l + 1 are adjacent in the table
+      constexpr int k1 = decltype(K1)::value;
+      const v4 w = ld4(tw1 + 2 * (k1 * G::R2 + 2 * l));
+      st.y[0][k1] = cmul(st.y[0][k1], w.xy);
+      st.y[1][k1] = cmul(st.y[1][k1], w.zw);
     });
   }
 }
@@ -299,10 +332,10 @@ SED_HD int lane_slot_bin(int l, int t) {
 }
 
 // Stage-2 FFTs, real-FFT split and |X|^2 (or |X|) into the frame's power row pw[0..NC].
-// tw2[t*LPF + l] = W_NFFT^(lane_slot_bin(l, t)).
+// tw2: W_NFFT^(lane_slot_bin(l, t)) at tw2_slot(t, l).
 // With E = U + conj V, O = -i (U - conj V), T = W O:  X[k] = E + T,  conj X[NC-k] = E - T.
 template <class G, bool MAGNITUDE>
-SED_HD void lane_stage2_power(LaneState<G>& st, float* pw, const cplx* tw2, int l) {
+SED_HD void lane_stage2_power(LaneState<G>& st, float* pw, const float* tw2, int l) {
   fft_dit<G::R2>(st.p);
   fft_dit<G::R2>(st.q);
   const bool l0 = (l == 0);
@@ -312,8 +345,11 @@ SED_HD void lane_stage2_power(LaneState<G>& st, float* pw, const cplx* tw2, int 
   float* hi_p = pw + G::R1 - l;         // pw[NC - k] of P slots at hi_p[R1 (R2-1-s)]
   float* hi_q = hi_p - off;
   const v2 k = v2{1.0f, -1.0f};
+  const float* srow = tw2 + l * G::SROW;
+  v4 wpair = v4{0.0f, 0.0f, 0.0f, 0.0f};
   static_for<0, G::SLOTS>([&](auto Tf) {
     constexpr int t = decltype(Tf)::value;
+    if constexpr (t % 2 == 0) wpair = ld4(srow + 2 * t);  // twiddles of slots t and t + 1
     constexpr bool qslot = t > G::R2 / 2;
     constexpr int s = qslot ? t - 1 : t;
     v2 u, v;
@@ -326,7 +362,7 @@ SED_HD void lane_stage2_power(LaneState<G>& st, float* pw, const cplx* tw2, int 
     }
     const v2 e = pk_fma(v, k, u);             // (ur + vr, ui - vi)
     const v2 o = pk_fma(swp(u), k, swp(v));   // (ui + vi, vr - ur)
-    const v2 tt = cmul(o, ld2(tw2 + t * G::LPF + l));
+    const v2 tt = cmul(o, t % 2 == 0 ? wpair.xy : wpair.zw);
     const v2 re = pk_fma(lo2(tt), k, lo2(e)); // (Re X[k], Re X[NC-k])
     const v2 im = pk_fma(hi2(tt), k, hi2(e)); // (Im X[k], -Im X[NC-k])
     v2 pp = pk_fma(im, im, re * re);

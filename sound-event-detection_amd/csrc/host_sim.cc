@@ -17,10 +17,21 @@ double run_one(unsigned seed, int win_length, bool left) {
   std::vector<float> frame(G::NFFT);
   for (auto& v : frame) v = nd(rng);
   const auto wd = build_window(G::NFFT, win_length, left);
-  std::vector<float> win(G::NFFT);
-  for (int i = 0; i < G::NFFT; ++i) win[i] = (float)(0.5 * wd[i]);
-  const auto tw1 = build_tw1<G>();
-  const auto tw2 = build_tw2<G>();
+  // tables in the layout the kernel keeps in LDS
+  std::vector<float> win(G::WIN_FLOATS, 0.0f), tw1(G::TW1_FLOATS, 0.0f), tw2(G::TW2_FLOATS, 0.0f);
+  for (int i = 0; i < G::NFFT; ++i) win[win_slot<G>(i)] = (float)(0.5 * wd[i]);
+  const auto t1 = build_tw1<G>();
+  const auto t2 = build_tw2<G>();
+  for (int k1 = 0; k1 < G::R1; ++k1)
+    for (int n2 = 0; n2 < G::R2; ++n2) {
+      tw1[tw1_slot<G>(k1, n2)] = t1[k1 * G::R2 + n2].x;
+      tw1[tw1_slot<G>(k1, n2) + 1] = t1[k1 * G::R2 + n2].y;
+    }
+  for (int t = 0; t < G::SLOTS; ++t)
+    for (int l = 0; l < G::LPF; ++l) {
+      tw2[tw2_slot<G>(t, l)] = t2[t * G::LPF + l].x;
+      tw2[tw2_slot<G>(t, l) + 1] = t2[t * G::LPF + l].y;
+    }
   std::vector<LaneState<G>> st(G::LPF);
   std::vector<float> xfr(G::XFR, 0.0f), pw(G::PP, -1.0f);
   for (int l = 0; l < G::LPF; ++l) lane_stage1<G>(st[l], SrcF32{frame.data()}, win.data(), tw1.data(), l);

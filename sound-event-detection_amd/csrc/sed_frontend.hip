@@ -27,6 +27,7 @@ using Geo1024 = Geo<32, 16, 16, 12>;
 using Geo2048 = Geo<32, 32, 16, 4>;
 
 constexpr int kMaxMelSets = 4;
+constexpr int kMelBurst = 8;    // steps of 4 bins whose MFMA operands are fetched from LDS in one burst
 constexpr int kPartStride = 20;  // floats between the partial sums of consecutive positions: [frame][filter] + pad (4*odd: bank spread)
 
 // Timing ablations: build with -DSED_ABLATION and set SED_DEBUG_SKIP=<mask> to leave phases of the streaming loop
@@ -72,7 +73,7 @@ struct FrontParams {
 __device__ __forceinline__ unsigned long long sed_stamp() {
   unsigned long long t;
   __builtin_amdgcn_sched_barrier(0);
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
   __builtin_amdgcn_sched_barrier(0);
   return t;
 }
@@ -179,9 +180,8 @@ __device__ __forceinline__ int mel_gather_word(const FrontParams& p, const int32
 // Mel projection of 4 frames (power rows prow0 + j*PITCH, j = 0..3) on the matrix pipe.
 // Lane 4*block + j feeds the power of frame j as the B operand and the weight of filter 4*quad + j as the
 // A operand of block `block`; after the last instruction it holds, in acc[i], the partial sum of filter
-// 4*quad + i for frame j over the bins of position (set, block).  Operands are fetched two steps of 4 bins ahead of
-// the instructions that consume them; the weight table carries one all-zero step per set, so an odd step count
-// needs no branch.  The partial sums go to LDS, kPartStride floats per position.
+// 4*quad + i for frame j over the bins of position (set, block).  The weight table carries one all-zero step per
+// set, so an odd step count needs no special case.  The partial sums go to LDS, kPartStride floats per position.
 __device__ __forceinline__ void mel_mfma_4frames(const FrontParams& p, const int32_t* boffL, const float* prow0,
                                                  const float* mela, float* part, int lane) {
   asm volatile("" : "+v"(lane));  // keeps the per-lane table reads inside the streaming loop instead of pinning registers
@@ -191,20 +191,29 @@ __device__ __forceinline__ void mel_mfma_4frames(const FrontParams& p, const int
     const float* bp = prow0 + boffL[s * 64 + lane];
     const float* ap = mela + ((size_t)s * (U + 1) * 64 + lane) * 4;
     v4 acc = v4{0.0f, 0.0f, 0.0f, 0.0f};
-    v4 a0 = ld4(ap), b0 = ld4(bp);
-    v4 a1 = ld4(ap + 256 * min(1, U)), b1 = ld4(bp + 4 * min(1, U - 1));
-    for (int u = 0; u < U; u += 2) {
-      const v4 na0 = ld4(ap + 256 * min(u + 2, U)), nb0 = ld4(bp + 4 * min(u + 2, U - 1));
-      const v4 na1 = ld4(ap + 256 * min(u + 3, U)), nb1 = ld4(bp + 4 * min(u + 3, U - 1));
-      acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.x, b0.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.y, b0.y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.z, b0.z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.w, b0.w, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.x, b1.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.y, b1.y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.z, b1.z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.w, b1.w, acc, 0, 0, 0);
-      a0 = na0; b0 = nb0; a1 = na1; b1 = nb1;
+    for (int u0 = 0; u0 < U; u0 += kMelBurst) {
+      // one burst of LDS reads for kMelBurst steps of 4 bins (steps past the end read the all-zero weights), then
+      // the instructions, two steps per (wave-uniform) test
+      v4 a[kMelBurst], b[kMelBurst];
+      static_for<0, kMelBurst>([&](auto Uf) {
+        constexpr int k = decltype(Uf)::value;
+        a[k] = ld4(ap + 256 * min(u0 + k, U));
+        b[k] = ld4(bp + 4 * min(u0 + k, U - 1));
+      });
+      SED_SCHED_FENCE();  // the whole burst is in flight before the first instruction waits for its operands
+      static_for<0, kMelBurst / 2>([&](auto Pf) {
+        constexpr int k = 2 * decltype(Pf)::value;
+        if (u0 + k < U) {
+          acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[k].x, b[k].x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[k].y, b[k].y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[k].z, b[k].z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[k].w, b[k].w, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[k + 1].x, b[k + 1].x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[k + 1].y, b[k + 1].y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[k + 1].z, b[k + 1].z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[k + 1].w, b[k + 1].w, acc, 0, 0, 0);
+        }
+      });
     }
     st4(part + (s * 16 + blk) * kPartStride + j * 4, acc);
   }
@@ -228,11 +237,18 @@ __device__ __forceinline__ v4 mel_gather_log(const FrontParams& p, const int32_t
     });
     sum += (v[0] + v[1]) + (v[2] + v[3]);
   }
-  v4 val;
-  val.x = log_epilogue(sum.x, p.log_kind, p.amin, p.db_offset, p.ln_offset);
-  val.y = log_epilogue(sum.y, p.log_kind, p.amin, p.db_offset, p.ln_offset);
-  val.z = log_epilogue(sum.z, p.log_kind, p.amin, p.db_offset, p.ln_offset);
-  val.w = log_epilogue(sum.w, p.log_kind, p.amin, p.db_offset, p.ln_offset);
+  v4 val = sum;
+  if (p.log_kind == SED_LOG_DB10) {
+    val.x = 3.0102999566398120f * __log2f(fmaxf(sum.x, p.amin)) - p.db_offset;
+    val.y = 3.0102999566398120f * __log2f(fmaxf(sum.y, p.amin)) - p.db_offset;
+    val.z = 3.0102999566398120f * __log2f(fmaxf(sum.z, p.amin)) - p.db_offset;
+    val.w = 3.0102999566398120f * __log2f(fmaxf(sum.w, p.amin)) - p.db_offset;
+  } else if (p.log_kind == SED_LOG_LN) {
+    val.x = 0.6931471805599453f * __log2f(sum.x + p.ln_offset);
+    val.y = 0.6931471805599453f * __log2f(sum.y + p.ln_offset);
+    val.z = 0.6931471805599453f * __log2f(sum.z + p.ln_offset);
+    val.w = 0.6931471805599453f * __log2f(sum.w + p.ln_offset);
+  }
   const int m0 = 4 * (16 * r + (lane >> 2));
   if (p.affine) val = __builtin_elementwise_fma(val, ld4(affL + m0), ld4(affL + 128 + m0));
   return val;
@@ -265,8 +281,8 @@ stft_mel_kernel(const FrontParams p) {
   const int fi = lane / G::LPF, l = lane % G::LPF;
 
   float* winL = smem + p.off_win;
-  cplx* tw1L = (cplx*)(smem + p.off_tw1);
-  cplx* tw2L = (cplx*)(smem + p.off_tw2);
+  float* tw1L = smem + p.off_tw1;
+  float* tw2L = smem + p.off_tw2;
   float* melaL = smem + p.off_mela;
   int32_t* melbaseL = (int32_t*)(smem + p.off_melbase);
   int32_t* quadposL = (int32_t*)(smem + p.off_quadpos);
@@ -276,9 +292,19 @@ stft_mel_kernel(const FrontParams p) {
   float* zeroL = smem + p.off_zero;
   float* X = smem + p.off_wave + wave * p.wave_floats;
 
-  for (int i = tid; i < G::NFFT; i += NT) winL[i] = p.window[i];
-  for (int i = tid; i < G::R1 * G::R2; i += NT) tw1L[i] = p.tw1[i];
-  for (int i = tid; i < G::SLOTS * G::LPF; i += NT) tw2L[i] = p.tw2[i];
+  // tables: natural order in global memory, lane-major (see Geo) in LDS; padding entries are never read
+  for (int i = tid; i < G::NFFT; i += NT) winL[win_slot<G>(i)] = p.window[i];
+  for (int i = tid; i < G::R1 * G::R2; i += NT) {
+    const cplx w = p.tw1[i];
+    float* d = tw1L + tw1_slot<G>(i / G::R2, i % G::R2);
+    d[0] = w.x; d[1] = w.y;
+  }
+  for (int i = tid; i < G::LPF * (G::SLOTS + 1); i += NT) {
+    const int t = i / G::LPF, l = i % G::LPF;
+    const cplx w = t < G::SLOTS ? p.tw2[i] : cplx{0.0f, 0.0f};  // the odd slot count is padded: slots are read in pairs
+    float* d = tw2L + tw2_slot<G>(t, l);
+    d[0] = w.x; d[1] = w.y;
+  }
   if constexpr (!SPEC_OUT) {
     for (int i = tid; i < p.mel_sets * (p.mel_u + 1) * 256; i += NT) melaL[i] = p.mela[i];
     if (p.affine)
@@ -328,6 +354,7 @@ stft_mel_kernel(const FrontParams p) {
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       wave_phase_fence();
+      SED_STAMP(0)
       if constexpr (!SPEC_OUT) {
         if (held) {
           static_for<0, kGroups>([&](auto Gf) {
@@ -699,9 +726,9 @@ static int launch_front(const sed_plan* pl, FrontParams p, int64_t B, hipStream_
   p.wave_floats = round64(std::max(std::max(256 * p.span_blocks, G::FPW * G::XFR), p.part_off + part_floats));
   // shared tables
   int off = 0;
-  p.off_win = off; off += G::NFFT;
-  p.off_tw1 = off; off += 2 * G::R1 * G::R2;
-  p.off_tw2 = off; off += round4(2 * G::SLOTS * G::LPF);
+  p.off_win = off; off += G::WIN_FLOATS;
+  p.off_tw1 = off; off += G::TW1_FLOATS;
+  p.off_tw2 = off; off += G::TW2_FLOATS;
   p.off_mela = off; off += SPEC_OUT ? 0 : p.mel_sets * (p.mel_u + 1) * 256;
   p.off_melbase = off; off += SPEC_OUT ? 0 : round4(p.mel_sets * 16);
   p.off_quadpos = off; off += SPEC_OUT ? 0 : round4(p.n_quads);
@@ -749,7 +776,7 @@ static int launch_front(const sed_plan* pl, FrontParams p, int64_t B, hipStream_
     (void)hipMemcpy(h.data(), d_stamps, n_st * sizeof(unsigned long long), hipMemcpyDeviceToHost);
     double sum[8] = {0};
     for (size_t w = 0; w < n_st / 8; ++w) for (int k = 0; k < 8; ++k) sum[k] += (double)h[w * 8 + k];
-    const char* names[8] = {"stage(global->LDS)", "stage1 fft+twiddle", "halo move", "exchange", "stage2+power", "mel (mfma+gather+log)", "store", "-"};
+    const char* names[8] = {"wait for the span", "stage 1", "-", "exchange", "stage 2 + power", "mel", "loop end", "-"};
     double tot = 0; for (int k = 0; k < 8; ++k) tot += sum[k];
     for (int k = 0; k < 7; ++k) fprintf(stderr, "STAMP %-24s %10.0f cycles/wave  %5.1f%%\n", names[k], sum[k] / (n_st / 8), 100.0 * sum[k] / tot);
     fprintf(stderr, "STAMP total %10.0f cycles/wave over %zu waves\n", tot / (n_st / 8), n_st / 8);
