@@ -174,6 +174,37 @@ def test_edges_ragged_short_empty_strided():
     assert torch.equal(fe(big[1:2, 1:]), a[1:2])                          # batch position does not matter
 
 
+def test_mel_counts_hops_and_affine_variants():
+    """Mel counts that are not multiples of 4 (scalar stores, partial last quad), more than 64 filters (two gather
+    rounds), hops that change the staging path (span wider than 2048 samples), and the affine epilogue on them."""
+    import sed_amd
+    dev = _dev()
+    x = of.synth_batch(3, 40000, 32000, first=60)
+    xt = torch.from_numpy(x).to(dev)
+    for n_mels, hop, n_fft in ((3, 320, 1024), (30, 320, 1024), (65, 320, 1024), (128, 320, 1024), (64, 1024, 1024),
+                               (64, 512, 1024), (50, 160, 512), (128, 256, 2048)):
+        cfg = sed_amd.FrontendConfig.htsat(window_size=n_fft, hop_size=hop, mel_bins=n_mels)
+        fe = sed_amd.LogMelFrontend(cfg, layout="btm")
+        y = fe(xt)
+        gold = of.htsat_logmel(x, n_fft=n_fft, hop=hop, n_mels=n_mels, mode="gold")[:, 0]
+        ref32 = of.htsat_logmel(x, n_fft=n_fft, hop=hop, n_mels=n_mels, mode="ref32")[:, 0]
+        assert y.shape == gold.shape, (n_mels, hop, n_fft)
+        _check(y.cpu().numpy(), gold, ref32, NEAR_DB)
+        scale = torch.linspace(0.5, 2.0, n_mels)
+        shift = torch.linspace(-3.0, 3.0, n_mels)
+        fe.set_affine(scale, shift)
+        ya = fe(xt)
+        want = y * scale.to(dev) + shift.to(dev)
+        assert torch.max(torch.abs(ya - want)).item() < 1e-4, (n_mels, hop, n_fft)
+        out = torch.empty(3 * y.shape[1] * n_mels + 1, device=dev)[1:]      # output base that is only 4-byte aligned
+        fe.set_affine(None, None)
+        plan = fe._plan_for(xt.device)
+        from sed_amd import _lib as L
+        L.check(L.lib.sed_logmel_forward(plan.ptr, xt.data_ptr(), 3, xt.shape[1], xt.stride(0), out.data_ptr(),
+                                         y.shape[1] * n_mels, L.stream_ptr(xt.device)))
+        assert torch.equal(out.view(3, y.shape[1], n_mels), y), (n_mels, hop, n_fft)
+
+
 def test_state_dict_and_install_on_reference_shaped_model():
     import sed_amd
     from torch import nn
