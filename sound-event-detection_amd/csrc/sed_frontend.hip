@@ -43,7 +43,7 @@ struct FrontParams {
   const void* pcm;
   float* out;
   int64_t L, pcm_stride, out_stride_b;
-  int32_t T, hop, pad_left, pad_mode, pcm_kind, vec_ok;
+  int32_t T, hop, pad_left, pad_mode, pcm_kind;
   float pcm_div;
   int32_t n_mels, log_kind, affine;
   float amin, db_offset, ln_offset, inv_n_mels;
@@ -123,32 +123,36 @@ __device__ __attribute__((noinline)) void stage_span_edges(const void* pcm, int 
   }
 }
 
+// 16- and 8-byte global loads from addresses that are only aligned to the sample size (global memory accepts them).
+struct __attribute__((packed, aligned(4))) f32x4_u { float x, y, z, w; };
+struct __attribute__((packed, aligned(2))) i16x4_u { short x, y, z, w; };
+
 // One wavefront copies `count` samples (multiple of 4) of clip b, starting at padded-clip sample s0, to LDS.
-// The fast path issues its loads in batches of 8 x 16 B per lane before the first LDS store, with clamped
+// The fast path issues its loads in batches of 8 x 4 samples per lane before the first LDS store, with clamped
 // (never predicated) addresses: a load under a divergent branch would be waited for on its own.
 __device__ __forceinline__ void stage_span(const FrontParams& p, float* dst, int64_t b, int64_t s0, int count, int lane) {
-  const bool fast = s0 >= 0 && s0 + count <= p.L && p.vec_ok;
+  const bool fast = s0 >= 0 && s0 + count <= p.L;
   if (fast && p.pcm_kind == SED_PCM_F32) {
     const float* src = (const float*)p.pcm + b * p.pcm_stride + s0;
     for (int base = 0; base < count; base += 8 * 256) {
-      v4 v[8];
+      f32x4_u v[8];
       static_for<0, 8>([&](auto Kf) {
-        v[decltype(Kf)::value] = ld4(src + min(base + 256 * decltype(Kf)::value + 4 * lane, count - 4));
+        v[decltype(Kf)::value] = *reinterpret_cast<const f32x4_u*>(src + min(base + 256 * decltype(Kf)::value + 4 * lane, count - 4));
       });
       static_for<0, 8>([&](auto Kf) {
-        st4(dst + min(base + 256 * decltype(Kf)::value + 4 * lane, count - 4), v[decltype(Kf)::value]);
+        const f32x4_u w = v[decltype(Kf)::value];
+        st4(dst + min(base + 256 * decltype(Kf)::value + 4 * lane, count - 4), v4{w.x, w.y, w.z, w.w});
       });
     }
   } else if (fast) {
     const int16_t* src = (const int16_t*)p.pcm + b * p.pcm_stride + s0;
     for (int base = 0; base < count; base += 8 * 256) {
-      i16x4 v[8];
+      i16x4_u v[8];
       static_for<0, 8>([&](auto Kf) {
-        v[decltype(Kf)::value] =
-            *reinterpret_cast<const i16x4*>(src + min(base + 256 * decltype(Kf)::value + 4 * lane, count - 4));
+        v[decltype(Kf)::value] = *reinterpret_cast<const i16x4_u*>(src + min(base + 256 * decltype(Kf)::value + 4 * lane, count - 4));
       });
       static_for<0, 8>([&](auto Kf) {
-        const i16x4 w = v[decltype(Kf)::value];
+        const i16x4_u w = v[decltype(Kf)::value];
         st4(dst + min(base + 256 * decltype(Kf)::value + 4 * lane, count - 4),
             v4{(float)w.x / p.pcm_div, (float)w.y / p.pcm_div, (float)w.z / p.pcm_div, (float)w.w / p.pcm_div});
       });
@@ -832,9 +836,6 @@ static int front_forward(const sed_plan* pl, const void* pcm, int64_t B, int64_t
   p.n_quads = pl->n_quads;
   p.aff_scale = pl->d_scale;
   p.aff_shift = pl->d_shift;
-  const size_t esz = c.pcm_kind == SED_PCM_I16 ? 2 : 4;
-  const size_t need = c.pcm_kind == SED_PCM_I16 ? 8 : 16;
-  p.vec_ok = ((uintptr_t)pcm % need == 0) && ((pcm_stride * esz) % need == 0) ? 1 : 0;
   p.dma = (c.pcm_kind == SED_PCM_F32) && ((uintptr_t)pcm % 16 == 0) && (pcm_stride % 4 == 0) ? 1 : 0;  // hop, n_fft/2: multiples of 4
   p.out_vec = (c.n_mels % 4 == 0) && ((uintptr_t)out % 16 == 0) && (out_stride_b % 4 == 0) ? 1 : 0;
   static const int debug_skip = getenv("SED_DEBUG_SKIP") ? atoi(getenv("SED_DEBUG_SKIP")) : 0;
