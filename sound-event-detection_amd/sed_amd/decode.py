@@ -52,7 +52,7 @@ def threshold_runs(probs: torch.Tensor, threshold: float, smoothing=None):
     B, T, Cn = probs.shape
     cap = T // 2 + 1
     runs = torch.empty((B, Cn, cap, 2), dtype=torch.int32, device=probs.device)
-    counts = torch.zeros((B, Cn), dtype=torch.int32, device=probs.device)
+    counts = torch.empty((B, Cn), dtype=torch.int32, device=probs.device)   # the kernel writes every count
     with torch.cuda.device(probs.device):
         L.check(L.lib.sed_threshold_runs(probs.data_ptr(), B, T, Cn, float(np.float32(threshold)), _SMOOTH[smoothing],
                                          runs.data_ptr(), counts.data_ptr(), cap, L.stream_ptr(probs.device)),
@@ -101,7 +101,7 @@ def merge_runs(runs: torch.Tensor, counts: torch.Tensor, time_table: torch.Tenso
     cap = runs.shape[-2]
     n_groups = counts.numel()
     out_runs = torch.empty_like(runs)
-    out_counts = torch.zeros_like(counts)
+    out_counts = torch.empty_like(counts)                                   # the kernel writes every count
     with torch.cuda.device(runs.device):
         L.check(L.lib.sed_merge_runs(runs.data_ptr(), counts.data_ptr(), n_groups, cap, time_table.data_ptr(),
                                      time_table.numel(), float(gap), out_runs.data_ptr(), out_counts.data_ptr(),
