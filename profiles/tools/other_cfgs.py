@@ -1,0 +1,35 @@
+"""Times the front-end flavours other than the headline one (diagnostic)."""
+import sys, time, torch, numpy as np
+sys.path.insert(0, "sound-event-detection_amd")
+import sed_amd
+dev = torch.device("cuda", 0)
+def timeit(fn, n=30):
+    for _ in range(5): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+g = torch.Generator().manual_seed(0)
+cases = [
+  ("htsat f32 256x320000", sed_amd.FrontendConfig.htsat(), torch.randn(256, 320000, generator=g) * 0.1),
+  ("htsat i16 256x320000", sed_amd.FrontendConfig.htsat(pcm_kind=1), (torch.randn(256, 320000, generator=g) * 3000).to(torch.int16)),
+  ("htsat f32 unaligned rows", sed_amd.FrontendConfig.htsat(), None),
+  ("yamnet f32 512x160000", sed_amd.FrontendConfig.yamnet(), torch.randn(512, 160000, generator=g) * 0.1),
+  ("crnn f32 128x441000", sed_amd.FrontendConfig.crnn(), torch.randn(128, 441000, generator=g) * 0.1),
+  ("db_mel f32 128x441000", sed_amd.FrontendConfig.db_mel(), torch.randn(128, 441000, generator=g) * 0.1),
+]
+for name, cfg, x in cases:
+    if x is None:
+        base = (torch.randn(256, 320001, generator=g) * 0.1).to(dev)
+        x = base[:, 1:]
+    else:
+        x = x.to(dev)
+    fe = sed_amd.LogMelFrontend(cfg, layout="btm")
+    y = fe(x)
+    us = timeit(lambda: fe(x))
+    esz = 2 if x.dtype == torch.int16 else 4
+    byts = x.shape[0] * x.shape[1] * esz + y.numel() * 4
+    hours = x.shape[0] * x.shape[1] / cfg.sample_rate / 3600
+    print(f"{name:28s} {us:8.1f} us  {byts/us/1e6:7.2f} TB/s algorithmic  {hours/(us*1e-6):9.0f} audio-h/s  frames {y.shape[1]}")
