@@ -32,6 +32,9 @@ constexpr int kPartStride = 20;  // floats between the partial sums of consecuti
 
 // Timing ablations: build with -DSED_ABLATION and set SED_DEBUG_SKIP=<mask> to leave phases of the streaming loop
 // out (results are then garbage).  In normal builds the tests below fold to false.
+#if defined(SED_ABLATION) || defined(SED_STAMPS)
+#define SED_DIAGNOSTIC_BUILD 1  // diagnostic builds read SED_DEBUG_WAVES / SED_DEBUG_CHUNK / SED_DEBUG_SKIP from the environment
+#endif
 #ifdef SED_ABLATION
 #define SED_SKIP(p, bit) (((p).skip & (bit)) != 0)
 #else
@@ -743,8 +746,10 @@ static int launch_front(const sed_plan* pl, FrontParams p, int64_t B, hipStream_
   p.off_wave = round64(off);
   // as many wavefronts per workgroup as the geometry allows and LDS holds
   int waves = G::WAVES;
+#ifdef SED_DIAGNOSTIC_BUILD
   static const int debug_waves = getenv("SED_DEBUG_WAVES") ? atoi(getenv("SED_DEBUG_WAVES")) : 0;
   if (debug_waves > 0) waves = std::min(waves, debug_waves);
+#endif
   while (waves > 1 && (size_t)(p.off_wave + waves * p.wave_floats) * sizeof(float) > 160 * 1024) --waves;
   const size_t lds_bytes = (size_t)(p.off_wave + waves * p.wave_floats) * sizeof(float);
   if (lds_bytes > 160 * 1024) return SED_ERR_BAD_ARG;
@@ -758,8 +763,10 @@ static int launch_front(const sed_plan* pl, FrontParams p, int64_t B, hipStream_
   int64_t cf = (total_frames + max_waves - 1) / max_waves;
   cf = std::max<int64_t>(cf, 4 * G::FPW);
   cf = (cf + G::FPW - 1) / G::FPW * G::FPW;
+#ifdef SED_DIAGNOSTIC_BUILD
   static const int debug_chunk = getenv("SED_DEBUG_CHUNK") ? atoi(getenv("SED_DEBUG_CHUNK")) : 0;
   if (debug_chunk > 0) cf = debug_chunk;
+#endif
   cf = std::min<int64_t>(cf, ((int64_t)p.T + G::FPW - 1) / G::FPW * G::FPW);
   p.chunk_frames = (int32_t)cf;
   p.chunks_per_clip = (int32_t)((p.T + cf - 1) / cf);
@@ -838,8 +845,10 @@ static int front_forward(const sed_plan* pl, const void* pcm, int64_t B, int64_t
   p.aff_shift = pl->d_shift;
   p.dma = (c.pcm_kind == SED_PCM_F32) && ((uintptr_t)pcm % 16 == 0) && (pcm_stride % 4 == 0) ? 1 : 0;  // hop, n_fft/2: multiples of 4
   p.out_vec = (c.n_mels % 4 == 0) && ((uintptr_t)out % 16 == 0) && (out_stride_b % 4 == 0) ? 1 : 0;
+#ifdef SED_DIAGNOSTIC_BUILD
   static const int debug_skip = getenv("SED_DEBUG_SKIP") ? atoi(getenv("SED_DEBUG_SKIP")) : 0;
   p.skip = debug_skip;
+#endif
   hipStream_t s = (hipStream_t)stream;
   const bool mag = c.spectrum == SED_SPEC_MAGNITUDE;
 #define SED_DISPATCH(GEO)                                                         \
