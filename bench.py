@@ -50,6 +50,9 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
+                    "rehearse the multi-rank control flow on a box with one GPU, together with --one-device)")
+    ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -58,13 +61,24 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device: the hot path has no CPU fallback")
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     import sed_amd
     from sed_amd import decode as D
+
+    trace = os.environ.get("SED_BENCH_TRACE")
+
+    def say(msg):
+        if trace:
+            print(f"[rank {rank}] {msg}", file=sys.stderr, flush=True)
 
     L = SR * CLIP_S
     fe = sed_amd.LogMelFrontend(sed_amd.FrontendConfig.htsat())
@@ -88,10 +102,14 @@ def main():
         mruns, mcounts = D.merge_runs(runs, counts, table, 0.6)
         buf = torch.cat([mcounts[..., None], mruns.flatten(-2)], -1)
         if world > 1:
-            out, work = sed_amd.sharding.all_gather_events(buf, async_op=True)
+            # (the gloo rehearsal gathers host copies: gloo's device-tensor path stalls after a few async gathers)
+            src = buf if args.backend == "nccl" else buf.cpu()
+            out, work = sed_amd.sharding.all_gather_events(src, async_op=True)
             pending.append((out, work))
+            say(f"step {i}: gather issued, {len(pending)} pending")
             if len(pending) > 4:
                 pending.pop(0)[1].wait()
+                say(f"step {i}: oldest gather done")
         return y, buf
 
     def fence():
@@ -102,13 +120,18 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    say("setup done")
     for _ in range(args.warmup):
         step()
+    say("warm-up issued")
     fence()
+    say("warm-up fenced")
     t0 = time.perf_counter()
     for i in range(args.steps):
         y, buf = step(i)
+    say("steps issued")
     fence()
+    say("steps fenced")
     elapsed = time.perf_counter() - t0
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
