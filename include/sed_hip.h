@@ -31,10 +31,11 @@ typedef enum sed_status {
 
 enum { SED_PAD_NONE = 0, SED_PAD_CONSTANT = 1, SED_PAD_REFLECT = 2 };     /* centre padding mode   */
 enum { SED_SPEC_MAGNITUDE = 1, SED_SPEC_POWER = 2 };
-enum { SED_MEL_SLANEY = 0, SED_MEL_HTK_TF = 1 };
-enum { SED_LOG_NONE = 0, SED_LOG_DB10 = 1, SED_LOG_LN = 2 };
+enum { SED_MEL_SLANEY = 0, SED_MEL_HTK_TF = 1, SED_MEL_KALDI = 2 };
+enum { SED_LOG_NONE = 0, SED_LOG_DB10 = 1, SED_LOG_LN = 2, SED_LOG_LN_FLOOR = 3 };
 enum { SED_PCM_F32 = 0, SED_PCM_I16 = 1 };
 enum { SED_WIN_CENTER = 0, SED_WIN_LEFT = 1 };
+enum { SED_WINDOW_HANN_PERIODIC = 0, SED_WINDOW_HANN_SYMMETRIC = 1 };
 enum { SED_SMOOTH_NONE = 0, SED_SMOOTH_MEDIAN3 = 1, SED_SMOOTH_GAUSS25 = 2 };
 
 /*
@@ -47,6 +48,11 @@ enum { SED_SMOOTH_NONE = 0, SED_SMOOTH_MEDIAN3 = 1, SED_SMOOTH_GAUSS25 = 2 };
  *           SLANEY 40 mel 0..22050, LN(1e-9)
  *   dB mel  (src/utils/audio_to_spectrograms.py:30-44): 44100/2048/2048/512, center, CONSTANT, POWER,
  *           SLANEY 64 mel 0..22050, DB10 then sed_db_normalize(per clip, top_db 80)
+ * and the Kaldi filterbank features of the Audio-Mamba classifier
+ *   AuM     (external/audio_mamba/src/dataloader.py:133-134, torchaudio.compliance.kaldi.fbank(htk_compat=True,
+ *           use_energy=False, window_type='hanning', num_mel_bins=128, dither=0, frame_shift=10)): sr/512/400/160 at
+ *           16 kHz, no centring, WIN_LEFT, HANN_SYMMETRIC, remove_dc 1, preemphasis 0.97, POWER, KALDI 128 mel
+ *           20..sr/2, LN_FLOOR(amin = FLT_EPSILON)
  */
 typedef struct sed_frontend_cfg {
   int32_t sample_rate;
@@ -67,6 +73,9 @@ typedef struct sed_frontend_cfg {
   float ln_offset;          /* LN: ln(x + ln_offset)                                               */
   int32_t pcm_kind;         /* SED_PCM_*                                                           */
   float pcm_divisor;        /* I16: sample / pcm_divisor (32767 or 32768)                          */
+  int32_t window_kind;      /* SED_WINDOW_*                                                        */
+  int32_t remove_dc;        /* 1: subtract the mean of the win_length samples of each frame        */
+  float preemphasis;        /* c > 0: y[n] = x[n] - c*x[n-1] inside each frame, x[-1] := x[0]; 0: off */
 } sed_frontend_cfg;
 
 typedef struct sed_plan sed_plan;
@@ -81,12 +90,17 @@ const char* sed_status_string(int status);
 /* Mel filterbank as the reference modules hold it: melW[k*n_mels + m], k = 0..n_fft/2.
  * SED_MEL_SLANEY = librosa.filters.mel(htk=False, norm='slaney').T, the buffer logmel_extractor.melW built at
  * external/hts_audio_transformer/model/htsat.py:457; SED_MEL_HTK_TF = tf.signal.linear_to_mel_weight_matrix
- * (the YAMNet graph behind src/models/yamnet_train.py:47).  fp64 arithmetic, rounded once to fp32. */
+ * (the YAMNet graph behind src/models/yamnet_train.py:47); SED_MEL_KALDI = torchaudio.compliance.kaldi.get_mel_banks
+ * (low_freq fmin, high_freq fmax, no VTLN) with a zero row for the Nyquist bin, as kaldi.fbank applies it
+ * (external/audio_mamba/src/dataloader.py:133).  fp64 arithmetic, rounded once to fp32. */
 int sed_mel_filterbank(int32_t mel_kind, int32_t sample_rate, int32_t n_fft, int32_t n_mels, float fmin, float fmax,
                        float* melW_host);
 
 /* Periodic Hann of win_length inside n_fft samples (centred or left aligned), fp32 [n_fft]. */
 int sed_hann_window(int32_t n_fft, int32_t win_length, int32_t win_align, float* window_host);
+/* Same with the window kind chosen: SED_WINDOW_HANN_SYMMETRIC = torch.hann_window(win_length, periodic=False),
+ * the 'hanning' window of torchaudio.compliance.kaldi (external/audio_mamba/src/dataloader.py:133). */
+int sed_window(int32_t window_kind, int32_t n_fft, int32_t win_length, int32_t win_align, float* window_host);
 
 /* ---- plans (host side; tables are built in fp64 on the host and uploaded once) ---------------------- */
 

@@ -306,6 +306,86 @@ def librosa_db_mel(y, sr=44100, n_fft=2048, hop=512, n_mels=64, mode="gold", pad
 # ----------------------------------------------------------------------------
 
 
+# ----------------------------------------------------------------------------
+# F6 : Kaldi filterbank features of the Audio-Mamba classifier
+#      (external/audio_mamba/src/dataloader.py:94-152: torchaudio.compliance.kaldi.fbank; torchaudio is not
+#      installed here, so this restates its published algorithm: PARITY UNPINNED)
+# ----------------------------------------------------------------------------
+
+def kaldi_mel_banks(num_bins, window_length_padded, sample_freq, low_freq=20.0, high_freq=0.0, dtype=np.float64):
+    """torchaudio.compliance.kaldi.get_mel_banks with vtln_warp 1.0, plus the zero Nyquist column kaldi.fbank pads:
+    (num_bins, window_length_padded // 2 + 1)."""
+    dt = dtype
+    num_fft_bins = window_length_padded // 2
+    nyquist = 0.5 * sample_freq
+    if high_freq <= 0.0:
+        high_freq += nyquist
+    fft_bin_width = dt(sample_freq) / dt(window_length_padded)
+
+    def mel_scale(f):
+        return dt(1127.0) * np.log(dt(1.0) + np.asarray(f, dtype=dt) / dt(700.0))
+
+    mel_low, mel_high = mel_scale(low_freq), mel_scale(high_freq)
+    delta = (mel_high - mel_low) / dt(num_bins + 1)
+    b = np.arange(num_bins, dtype=dt)[:, None]
+    left, center, right = mel_low + b * delta, mel_low + (b + dt(1.0)) * delta, mel_low + (b + dt(2.0)) * delta
+    mel = mel_scale(fft_bin_width * np.arange(num_fft_bins, dtype=dt))[None, :]
+    up = (mel - left) / (center - left)
+    down = (right - mel) / (right - center)
+    bins = np.maximum(dt(0.0), np.minimum(up, down)).astype(dt)
+    return np.pad(bins, ((0, 0), (0, 1)))
+
+
+def kaldi_fbank(x, sample_frequency=16000.0, num_mel_bins=128, frame_length=25.0, frame_shift=10.0, low_freq=20.0,
+                high_freq=0.0, preemphasis_coefficient=0.97, remove_dc_offset=True, mode="gold"):
+    """(B, L) -> (B, T, num_mel_bins), T = 1 + (L - window) // shift.  dither 0, use_energy False, hanning window,
+    power spectrum, log with the fp32 epsilon floor.  mode 'gold' = fp64 throughout, 'ref32' = fp32 arithmetic in
+    torchaudio's order of operations, fp32 FFT included."""
+    x = np.atleast_2d(np.asarray(x))
+    dt = np.float64 if mode == "gold" else np.float32
+    win = int(sample_frequency * frame_length * 0.001)
+    hop = int(sample_frequency * frame_shift * 0.001)
+    n_fft = 1 << max(1, (win - 1).bit_length())
+    B, L = x.shape
+    if L < win:
+        return np.zeros((B, 0, num_mel_bins), dtype=dt)
+    T = 1 + (L - win) // hop
+    idx = hop * np.arange(T)[:, None] + np.arange(win)[None, :]
+    fr = x.astype(dt)[:, idx]                                              # (B, T, win)
+    if remove_dc_offset:
+        fr = fr - fr.mean(axis=-1, keepdims=True, dtype=dt)
+    if preemphasis_coefficient != 0.0:
+        prev = np.concatenate([fr[..., :1], fr[..., :-1]], axis=-1)         # replicate padding on the left
+        fr = fr - dt(preemphasis_coefficient) * prev
+    n = np.arange(win, dtype=np.float64)
+    window = (0.5 - 0.5 * np.cos(2.0 * np.pi * n / (win - 1))).astype(dt)   # torch.hann_window(win, periodic=False)
+    fr = fr * window
+    fr = np.pad(fr, ((0, 0), (0, 0), (0, n_fft - win)))
+    spec = np.fft.rfft(fr, axis=-1)          # numpy >= 2 transforms fp32 input in fp32, as torch.fft.rfft does
+    assert spec.dtype == (np.complex128 if mode == "gold" else np.complex64)
+    power = (np.abs(spec).astype(dt)) ** 2
+    banks = kaldi_mel_banks(num_mel_bins, n_fft, sample_frequency, low_freq, high_freq, dtype=dt)
+    mel = power @ banks.T.astype(dt)
+    eps = dt(np.finfo(np.float32).eps)
+    return np.log(np.maximum(mel, eps))
+
+
+def aum_wav2fbank(x, sr, melbins=128, target_length=1024, fshift=10, norm_mean=None, norm_std=None, mode="gold"):
+    """AudiosetDataset._wav2fbank without mixup + the normalisation of __getitem__ (dataloader.py:94-152, 219-221)."""
+    x = np.atleast_2d(np.asarray(x))
+    dt = np.float64 if mode == "gold" else np.float32
+    x = x.astype(dt) - x.astype(dt).mean(axis=1, keepdims=True)
+    fb = kaldi_fbank(x, sample_frequency=sr, num_mel_bins=melbins, frame_shift=fshift, mode=mode)
+    n = fb.shape[1]
+    if n < target_length:
+        fb = np.pad(fb, ((0, 0), (0, target_length - n), (0, 0)))
+    else:
+        fb = fb[:, :target_length]
+    if norm_mean is not None and norm_std is not None:
+        fb = (fb - dt(norm_mean)) / (dt(norm_std) * 2)
+    return fb
+
+
 def synth_clip(clip_idx: int, n_samples: int, sr: int) -> np.ndarray:
     """Pink-ish noise + two sine bursts + 0.5 s of exact digital silence. fp32 in [-1, 1]."""
     rng = np.random.default_rng(1234 + clip_idx)

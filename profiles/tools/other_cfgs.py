@@ -19,6 +19,7 @@ cases = [
   ("yamnet f32 512x160000", sed_amd.FrontendConfig.yamnet(), torch.randn(512, 160000, generator=g) * 0.1),
   ("crnn f32 128x441000", sed_amd.FrontendConfig.crnn(), torch.randn(128, 441000, generator=g) * 0.1),
   ("db_mel f32 128x441000", sed_amd.FrontendConfig.db_mel(), torch.randn(128, 441000, generator=g) * 0.1),
+  ("kaldi fbank 16k 128 mel 512x160000", sed_amd.FrontendConfig.kaldi_fbank(16000.0, 128), torch.randn(512, 160000, generator=g) * 0.1),
 ]
 for name, cfg, x in cases:
     if x is None:

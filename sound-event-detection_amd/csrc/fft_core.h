@@ -285,6 +285,68 @@ SED_HD void lane_stage1(LaneState<G>& st, const Src src, const float* win, const
   }
 }
 
+// Kaldi framing (torchaudio.compliance.kaldi._get_window): sum of the lane's samples among the first win_length of
+// the frame (the mean over win_length samples is removed before pre-emphasis and windowing).
+template <class G>
+SED_HD float lane_frame_sum(const float* frame, int l, int win_length) {
+  float sum = 0.0f;
+  static_for<0, G::R1>([&](auto N1) {
+    constexpr int n1 = decltype(N1)::value;
+    const int base = 2 * G::R2 * n1 + 2 * G::A * l;
+    static_for<0, 2 * G::A>([&](auto Ef) {
+      constexpr int e = decltype(Ef)::value;
+      sum += (base + e < win_length) ? frame[base + e] : 0.0f;
+    });
+  });
+  return sum;
+}
+
+// Stage 1 with per-frame conditioning: y[n] = (x[n] - mean) - c (x[n-1] - mean), x[-1] := x[0], then window, FFT(s)
+// and inter-stage twiddle as in lane_stage1.  frame: the frame's samples in natural order (frame[-1] must be
+// readable; its value is not used).
+template <class G>
+SED_HD void lane_stage1_conditioned(LaneState<G>& st, const float* frame, const float* win, const float* tw1, int l,
+                                    float mean, float c) {
+  constexpr int LOG1 = ilog2(G::R1);
+  static_for<0, G::R1>([&](auto N1) {
+    constexpr int n1 = decltype(N1)::value;
+    constexpr int pos = bitrev(n1, LOG1);
+    const int base = 2 * G::R2 * n1 + 2 * G::A * l;
+    float x[2 * G::A + 1];
+    x[0] = frame[base == 0 ? 0 : base - 1];
+    static_for<0, 2 * G::A>([&](auto Ef) { x[decltype(Ef)::value + 1] = frame[base + decltype(Ef)::value]; });
+    float y[2 * G::A];
+    static_for<0, 2 * G::A>([&](auto Ef) {
+      constexpr int e = decltype(Ef)::value;
+      y[e] = (x[e + 1] - mean) - c * (x[e] - mean);
+    });
+    if constexpr (G::A == 1) {
+      st.y[0][pos] = v2{y[0], y[1]} * ld2(win + l * G::WROW + 2 * n1);  // lane-major window table
+    } else {
+      const v4 w = ld4(win + 2 * G::R2 * n1 + 4 * l);
+      st.y[0][pos] = v2{y[0], y[1]} * w.xy;
+      st.y[1][pos] = v2{y[2], y[3]} * w.zw;
+    }
+  });
+  if constexpr (G::A == 1) {
+    fft_dit<G::R1>(st.y[0]);
+    const float* trow = tw1 + l * G::TROW;
+    static_for<1, G::R1>([&](auto K1) {
+      constexpr int k1 = decltype(K1)::value;
+      st.y[0][k1] = cmul(st.y[0][k1], ld2(trow + 2 * k1));
+    });
+  } else {
+    fft_dit<G::R1>(st.y[0]);
+    fft_dit<G::R1>(st.y[1]);
+    static_for<1, G::R1>([&](auto K1) {
+      constexpr int k1 = decltype(K1)::value;
+      const v4 w = ld4(tw1 + 2 * (k1 * G::R2 + 2 * l));
+      st.y[0][k1] = cmul(st.y[0][k1], w.xy);
+      st.y[1][k1] = cmul(st.y[1][k1], w.zw);
+    });
+  }
+}
+
 // Exchange phase PH (0: k1 in [0, R1/2), 1: k1 in [R1/2, R1)): lane l writes row n2 of the frame's region.
 template <class G, int PH>
 SED_HD void lane_xwrite(const LaneState<G>& st, float* xfr, int l) {

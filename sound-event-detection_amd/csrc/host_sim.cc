@@ -57,6 +57,65 @@ double run_one(unsigned seed, int win_length, bool left) {
   return worst;
 }
 
+// Kaldi framing (DC removal over win_length samples, pre-emphasis, symmetric Hann, zero padding to n_fft) through the
+// conditioned stage 1, against the same steps in fp64 followed by a naive DFT.
+template <class G>
+double run_conditioned(unsigned seed, int win_length, float coef) {
+  std::mt19937 rng(seed);
+  std::normal_distribution<float> nd(0.05f, 0.3f);
+  std::vector<float> buf(G::NFFT + 1);
+  for (auto& v : buf) v = nd(rng);
+  const float* frame = buf.data() + 1;  // frame[-1] is readable
+  const auto wd = build_window(G::NFFT, win_length, true, true);
+  std::vector<float> win(G::WIN_FLOATS, 0.0f), tw1(G::TW1_FLOATS, 0.0f), tw2(G::TW2_FLOATS, 0.0f);
+  for (int i = 0; i < G::NFFT; ++i) win[win_slot<G>(i)] = (float)(0.5 * wd[i]);
+  const auto t1 = build_tw1<G>();
+  const auto t2 = build_tw2<G>();
+  for (int k1 = 0; k1 < G::R1; ++k1)
+    for (int n2 = 0; n2 < G::R2; ++n2) {
+      tw1[tw1_slot<G>(k1, n2)] = t1[k1 * G::R2 + n2].x;
+      tw1[tw1_slot<G>(k1, n2) + 1] = t1[k1 * G::R2 + n2].y;
+    }
+  for (int t = 0; t < G::SLOTS; ++t)
+    for (int l = 0; l < G::LPF; ++l) {
+      tw2[tw2_slot<G>(t, l)] = t2[t * G::LPF + l].x;
+      tw2[tw2_slot<G>(t, l) + 1] = t2[t * G::LPF + l].y;
+    }
+  float mean = 0.0f;
+  for (int l = 0; l < G::LPF; ++l) mean += lane_frame_sum<G>(frame, l, win_length);
+  mean *= 1.0f / (float)win_length;
+  std::vector<LaneState<G>> st(G::LPF);
+  std::vector<float> xfr(G::XFR, 0.0f), pw(G::PP, -1.0f);
+  for (int l = 0; l < G::LPF; ++l) lane_stage1_conditioned<G>(st[l], frame, win.data(), tw1.data(), l, mean, coef);
+  for (int l = 0; l < G::LPF; ++l) lane_xwrite<G, 0>(st[l], xfr.data(), l);
+  for (int l = 0; l < G::LPF; ++l) lane_xread<G, 0>(st[l], xfr.data(), l);
+  for (int l = 0; l < G::LPF; ++l) lane_xwrite<G, 1>(st[l], xfr.data(), l);
+  for (int l = 0; l < G::LPF; ++l) lane_xread<G, 1>(st[l], xfr.data(), l);
+  for (int l = 0; l < G::LPF; ++l) lane_stage2_power<G, false>(st[l], pw.data(), tw2.data(), l);
+  double mu = 0.0;
+  for (int n = 0; n < win_length; ++n) mu += frame[n];
+  mu /= win_length;
+  std::vector<double> y(G::NFFT, 0.0);
+  for (int n = 0; n < win_length; ++n) {
+    const double a = frame[n] - mu, b = frame[n == 0 ? 0 : n - 1] - mu;
+    y[n] = (a - (double)coef * b) * wd[n];
+  }
+  double worst = 0.0, scale = 0.0;
+  std::vector<double> ref(G::NBINS);
+  for (int k = 0; k <= G::NC; ++k) {
+    double re = 0, im = 0;
+    for (int n = 0; n < G::NFFT; ++n) {
+      const double a = -2.0 * kPi * (double)(((int64_t)n * k) % G::NFFT) / G::NFFT;
+      re += y[n] * std::cos(a);
+      im += y[n] * std::sin(a);
+    }
+    ref[k] = re * re + im * im;
+    scale = std::max(scale, ref[k]);
+  }
+  for (int k = 0; k <= G::NC; ++k) worst = std::max(worst, std::fabs((double)pw[k] - ref[k]) / scale);
+  return worst;
+}
+
 // Emulates the MFMA mel projection from its schedule tables and compares with the dense product.
 static double check_mel_schedule(int sr, int n_fft, int M, double fmin, double fmax, bool htk, int pitch) {
   const int F = n_fft / 2 + 1;
@@ -112,5 +171,8 @@ int main() {
     report(2048, "magnitude", run_one<Geo<32, 32, 16, 4>, true>(seed, 2048, false));
     report(2048, "power", run_one<Geo<32, 32, 16, 4>, false>(seed, 2048, false));
   }
+  report(512, "kaldi framing 400", run_conditioned<Geo<16, 16, 8, 12>>(7, 400, 0.97f));
+  report(1024, "kaldi framing 800", run_conditioned<Geo<32, 16, 16, 12>>(8, 800, 0.97f));
+  report(2048, "kaldi framing 1102", run_conditioned<Geo<32, 32, 16, 4>>(9, 1102, 0.97f));
   return bad;
 }

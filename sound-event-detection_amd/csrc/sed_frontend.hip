@@ -50,6 +50,9 @@ struct FrontParams {
   float pcm_div;
   int32_t n_mels, log_kind, affine;
   float amin, db_offset, ln_offset, inv_n_mels;
+  // per-frame conditioning of the Kaldi flavour: DC removal over win_length samples and pre-emphasis
+  int32_t remove_dc, win_length, pre_off;  // pre_off: floats from the start of the wave region to its partial-sum scratch
+  float preemph, inv_win_length;
   int32_t chunk_frames, chunks_per_clip, total_chunks;
   // per-wave LDS region, in floats: [exchange rows | power rows, then mel partial sums at part_off]; frames at clip
   // edges (padding) or in unaligned clips are first staged here, span floats for FPW frames
@@ -99,6 +102,7 @@ __device__ __forceinline__ void wave_phase_fence() {
 __device__ __forceinline__ float log_epilogue(float acc, int log_kind, float amin, float db_offset, float ln_offset) {
   if (log_kind == SED_LOG_DB10) return 3.0102999566398120f * __log2f(fmaxf(acc, amin)) - db_offset;
   if (log_kind == SED_LOG_LN) return 0.6931471805599453f * __log2f(acc + ln_offset);
+  if (log_kind == SED_LOG_LN_FLOOR) return 0.6931471805599453f * __log2f(fmaxf(acc, amin));
   return acc;
 }
 
@@ -255,6 +259,11 @@ __device__ __forceinline__ v4 mel_gather_log(const FrontParams& p, const int32_t
     val.y = 0.6931471805599453f * __log2f(sum.y + p.ln_offset);
     val.z = 0.6931471805599453f * __log2f(sum.z + p.ln_offset);
     val.w = 0.6931471805599453f * __log2f(sum.w + p.ln_offset);
+  } else if (p.log_kind == SED_LOG_LN_FLOOR) {
+    val.x = 0.6931471805599453f * __log2f(fmaxf(sum.x, p.amin));
+    val.y = 0.6931471805599453f * __log2f(fmaxf(sum.y, p.amin));
+    val.z = 0.6931471805599453f * __log2f(fmaxf(sum.z, p.amin));
+    val.w = 0.6931471805599453f * __log2f(fmaxf(sum.w, p.amin));
   }
   const int m0 = 4 * (16 * r + (lane >> 2));
   if (p.affine) val = __builtin_elementwise_fma(val, ld4(affL + m0), ld4(affL + 128 + m0));
@@ -277,7 +286,7 @@ __device__ __forceinline__ void mel_store(const FrontParams& p, float* dst, v4 v
   }
 }
 
-template <class G, bool MAG, bool SPEC_OUT>
+template <class G, bool MAG, bool SPEC_OUT, bool PRE>
 __global__ void __launch_bounds__(G::WAVES * 64) __attribute__((amdgpu_waves_per_eu(G::WAVES / 4, G::WAVES / 4)))
 stft_mel_kernel(const FrontParams p) {
   extern __shared__ __align__(16) float smem[];
@@ -371,7 +380,21 @@ stft_mel_kernel(const FrontParams p) {
           });
         }
       }
-      lane_stage1<G>(st, SrcF32{X + fi * p.hop}, winL, tw1L, l);
+      if constexpr (PRE) {
+        // Kaldi framing: the lanes of a frame pool their partial sums through LDS (fixed summation order), then
+        // every lane conditions its own samples with the frame mean.
+        float* pool = X + p.pre_off + fi * G::LPF;
+        pool[l] = lane_frame_sum<G>(X + fi * p.hop, l, p.win_length);
+        wave_phase_fence();
+        float mean = 0.0f;
+        if (p.remove_dc) {
+          for (int j = 0; j < G::LPF; ++j) mean += pool[j];
+          mean *= p.inv_win_length;
+        }
+        lane_stage1_conditioned<G>(st, X + fi * p.hop, winL, tw1L, l, mean, p.preemph);
+      } else {
+        lane_stage1<G>(st, SrcF32{X + fi * p.hop}, winL, tw1L, l);
+      }
       wave_phase_fence();
       SED_STAMP(1)
       float* xfr = X + fi * G::XFR;
@@ -575,6 +598,12 @@ static int upload_mel(sed_plan* pl) {
   return upload(&pl->d_melw16, s16.weights);
 }
 
+static std::vector<float> build_mel(int mel_kind, int sr, int n_fft, int n_mels, double fmin, double fmax) {
+  if (mel_kind == SED_MEL_HTK_TF) return mel_htk_tf(sr, n_fft, n_mels, fmin, fmax);
+  if (mel_kind == SED_MEL_KALDI) return mel_kaldi(sr, n_fft, n_mels, fmin, fmax);
+  return mel_slaney(sr, n_fft, n_mels, fmin, fmax);
+}
+
 extern "C" const char* sed_version(void) { return "sedhip 0.2.0 (gfx950)"; }
 
 extern "C" const char* sed_status_string(int status) {
@@ -593,18 +622,23 @@ extern "C" const char* sed_status_string(int status) {
 
 extern "C" int sed_mel_filterbank(int32_t mel_kind, int32_t sample_rate, int32_t n_fft, int32_t n_mels, float fmin,
                                   float fmax, float* melW) {
-  if (!melW || sample_rate < 1 || n_fft < 2 || n_mels < 1 || !(fmax > fmin) || fmin < 0.0f) return SED_ERR_BAD_ARG;
-  const std::vector<float> w = (mel_kind == SED_MEL_HTK_TF) ? mel_htk_tf(sample_rate, n_fft, n_mels, fmin, fmax)
-                                                            : mel_slaney(sample_rate, n_fft, n_mels, fmin, fmax);
+  if (!melW || sample_rate < 1 || n_fft < 2 || n_mels < 1 || fmin < 0.0f) return SED_ERR_BAD_ARG;
+  if (mel_kind == SED_MEL_KALDI ? !((fmax <= 0.0f ? fmax + 0.5f * sample_rate : fmax) > fmin) : !(fmax > fmin)) return SED_ERR_BAD_ARG;
+  const std::vector<float> w = build_mel(mel_kind, sample_rate, n_fft, n_mels, fmin, fmax);
   std::memcpy(melW, w.data(), w.size() * sizeof(float));
   return SED_OK;
 }
 
-extern "C" int sed_hann_window(int32_t n_fft, int32_t win_length, int32_t win_align, float* window) {
+extern "C" int sed_window(int32_t window_kind, int32_t n_fft, int32_t win_length, int32_t win_align, float* window) {
   if (!window || win_length < 1 || win_length > n_fft) return SED_ERR_BAD_ARG;
-  const std::vector<double> w = build_window(n_fft, win_length, win_align == SED_WIN_LEFT);
+  if (window_kind != SED_WINDOW_HANN_PERIODIC && window_kind != SED_WINDOW_HANN_SYMMETRIC) return SED_ERR_BAD_ARG;
+  const std::vector<double> w = build_window(n_fft, win_length, win_align == SED_WIN_LEFT, window_kind == SED_WINDOW_HANN_SYMMETRIC);
   for (int i = 0; i < n_fft; ++i) window[i] = (float)w[i];
   return SED_OK;
+}
+
+extern "C" int sed_hann_window(int32_t n_fft, int32_t win_length, int32_t win_align, float* window) {
+  return sed_window(SED_WINDOW_HANN_PERIODIC, n_fft, win_length, win_align, window);
 }
 
 extern "C" int sed_plan_create(const sed_frontend_cfg* cfg, sed_plan** out) {
@@ -616,13 +650,23 @@ extern "C" int sed_plan_create(const sed_frontend_cfg* cfg, sed_plan** out) {
   else if (cfg->n_fft == 2048) geo = 2;
   else return SED_ERR_UNSUPPORTED_NFFT;
   if (cfg->win_length < 1 || cfg->win_length > cfg->n_fft) return SED_ERR_BAD_ARG;
-  if (cfg->hop < 4 || cfg->hop % 4 != 0 || cfg->hop > cfg->n_fft) return SED_ERR_BAD_ARG;
+  if (cfg->hop < 1 || cfg->hop > cfg->n_fft) return SED_ERR_BAD_ARG;
+  // frames are read from LDS 8 or 16 bytes at a time: the hop must keep them aligned, except with per-frame
+  // conditioning, which reads sample by sample (Kaldi's 10 ms shift at 44.1 kHz is 441 samples)
+  if (cfg->hop % 4 != 0 && !(cfg->remove_dc || cfg->preemphasis > 0.0f)) return SED_ERR_BAD_ARG;
   if (cfg->n_mels < 1 || cfg->n_mels > 128 || cfg->sample_rate < 1) return SED_ERR_BAD_ARG;
   if (cfg->spectrum != SED_SPEC_MAGNITUDE && cfg->spectrum != SED_SPEC_POWER) return SED_ERR_BAD_ARG;
   if (cfg->center && cfg->pad_mode != SED_PAD_CONSTANT && cfg->pad_mode != SED_PAD_REFLECT) return SED_ERR_BAD_ARG;
   if (cfg->pcm_kind == SED_PCM_I16 && !(cfg->pcm_divisor > 0.0f)) return SED_ERR_BAD_ARG;
   if (cfg->tail_min_samples > 0 && cfg->tail_hop_samples < 1) return SED_ERR_BAD_ARG;
-  if (!(cfg->fmax > cfg->fmin) || cfg->fmin < 0.0f) return SED_ERR_BAD_ARG;
+  if (cfg->fmin < 0.0f) return SED_ERR_BAD_ARG;
+  if (cfg->mel_kind == SED_MEL_KALDI ? !((cfg->fmax <= 0.0f ? cfg->fmax + 0.5f * cfg->sample_rate : cfg->fmax) > cfg->fmin)
+                                     : !(cfg->fmax > cfg->fmin)) return SED_ERR_BAD_ARG;
+  if (cfg->window_kind != SED_WINDOW_HANN_PERIODIC && cfg->window_kind != SED_WINDOW_HANN_SYMMETRIC) return SED_ERR_BAD_ARG;
+  if (cfg->preemphasis < 0.0f || cfg->preemphasis >= 1.0f || (cfg->remove_dc != 0 && cfg->remove_dc != 1)) return SED_ERR_BAD_ARG;
+  // per-frame conditioning (Kaldi framing) is built for the power spectrum of uncentred, left-aligned frames
+  if ((cfg->remove_dc || cfg->preemphasis > 0.0f) &&
+      (cfg->center || cfg->win_align != SED_WIN_LEFT || cfg->spectrum != SED_SPEC_POWER)) return SED_ERR_BAD_ARG;
 
   sed_plan* pl = new (std::nothrow) sed_plan();
   if (!pl) return SED_ERR_BAD_ARG;
@@ -634,12 +678,11 @@ extern "C" int sed_plan_create(const sed_frontend_cfg* cfg, sed_plan** out) {
   if (rc) { delete pl; return rc; }
   pl->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 
-  pl->window_host = build_window(cfg->n_fft, cfg->win_length, cfg->win_align == SED_WIN_LEFT);
+  pl->window_host = build_window(cfg->n_fft, cfg->win_length, cfg->win_align == SED_WIN_LEFT,
+                                 cfg->window_kind == SED_WINDOW_HANN_SYMMETRIC);
   std::vector<float> wh(cfg->n_fft);
   for (int i = 0; i < cfg->n_fft; ++i) wh[i] = (float)(0.5 * pl->window_host[i]);
-  pl->melW_host = (cfg->mel_kind == SED_MEL_HTK_TF)
-                      ? mel_htk_tf(cfg->sample_rate, cfg->n_fft, cfg->n_mels, cfg->fmin, cfg->fmax)
-                      : mel_slaney(cfg->sample_rate, cfg->n_fft, cfg->n_mels, cfg->fmin, cfg->fmax);
+  pl->melW_host = build_mel(cfg->mel_kind, cfg->sample_rate, cfg->n_fft, cfg->n_mels, cfg->fmin, cfg->fmax);
   pl->db_offset = (float)(10.0 * std::log10(std::max((double)cfg->amin, (double)cfg->ref)));
 
   rc = upload(&pl->d_window, wh);
@@ -722,15 +765,17 @@ extern "C" int sed_plan_set_affine(sed_plan* pl, const float* scale, const float
 static inline int round4(int v) { return (v + 3) & ~3; }
 static inline int round64(int v) { return (v + 63) & ~63; }
 
-template <class G, bool MAG, bool SPEC_OUT>
+template <class G, bool MAG, bool SPEC_OUT, bool PRE_ = false>
 static int launch_front(const sed_plan* pl, FrontParams p, int64_t B, hipStream_t stream) {
+  constexpr bool PRE = PRE_;
   // per-wave LDS region
-  p.span = (G::FPW - 1) * p.hop + G::NFFT;
+  p.span = round4((G::FPW - 1) * p.hop + G::NFFT);
   p.span_blocks = (p.span + 255) / 256;
   p.part_off = G::FPW * G::PP;
   p.early = p.dma && !SPEC_OUT && 256 * p.span_blocks <= p.part_off;  // the span may land while the partial sums are in use
   const int part_floats = SPEC_OUT ? 0 : p.mel_sets * 16 * kPartStride;
-  p.wave_floats = round64(std::max(std::max(256 * p.span_blocks, G::FPW * G::XFR), p.part_off + part_floats));
+  p.pre_off = 256 * p.span_blocks;  // behind the staged span: FPW frames x LPF partial sums (Kaldi DC removal)
+  p.wave_floats = round64(std::max(std::max(256 * p.span_blocks + (PRE ? 64 : 0), G::FPW * G::XFR), p.part_off + part_floats));
   // shared tables
   int off = 0;
   p.off_win = off; off += G::WIN_FLOATS;
@@ -753,7 +798,7 @@ static int launch_front(const sed_plan* pl, FrontParams p, int64_t B, hipStream_
   while (waves > 1 && (size_t)(p.off_wave + waves * p.wave_floats) * sizeof(float) > 160 * 1024) --waves;
   const size_t lds_bytes = (size_t)(p.off_wave + waves * p.wave_floats) * sizeof(float);
   if (lds_bytes > 160 * 1024) return SED_ERR_BAD_ARG;
-  auto kern = stft_mel_kernel<G, MAG, SPEC_OUT>;
+  auto kern = stft_mel_kernel<G, MAG, SPEC_OUT, PRE>;
   SED_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds_bytes));
   // chunks: runs of consecutive frames of one clip, one wavefront each
@@ -831,6 +876,10 @@ static int front_forward(const sed_plan* pl, const void* pcm, int64_t B, int64_t
   p.amin = c.amin;
   p.db_offset = pl->db_offset;
   p.ln_offset = c.ln_offset;
+  p.remove_dc = c.remove_dc;
+  p.preemph = c.preemphasis;
+  p.win_length = c.win_length;
+  p.inv_win_length = 1.0f / (float)c.win_length;
   p.window = pl->d_window;
   p.tw1 = pl->d_tw1;
   p.tw2 = pl->d_tw2;
@@ -843,7 +892,7 @@ static int front_forward(const sed_plan* pl, const void* pcm, int64_t B, int64_t
   p.n_quads = pl->n_quads;
   p.aff_scale = pl->d_scale;
   p.aff_shift = pl->d_shift;
-  p.dma = (c.pcm_kind == SED_PCM_F32) && ((uintptr_t)pcm % 16 == 0) && (pcm_stride % 4 == 0) ? 1 : 0;  // hop, n_fft/2: multiples of 4
+  p.dma = (c.pcm_kind == SED_PCM_F32) && ((uintptr_t)pcm % 16 == 0) && (pcm_stride % 4 == 0) && (c.hop % 4 == 0) ? 1 : 0;  // n_fft/2: a multiple of 4
   p.out_vec = (c.n_mels % 4 == 0) && ((uintptr_t)out % 16 == 0) && (out_stride_b % 4 == 0) ? 1 : 0;
 #ifdef SED_DIAGNOSTIC_BUILD
   static const int debug_skip = getenv("SED_DEBUG_SKIP") ? atoi(getenv("SED_DEBUG_SKIP")) : 0;
@@ -851,6 +900,15 @@ static int front_forward(const sed_plan* pl, const void* pcm, int64_t B, int64_t
 #endif
   hipStream_t s = (hipStream_t)stream;
   const bool mag = c.spectrum == SED_SPEC_MAGNITUDE;
+  if (c.remove_dc || c.preemphasis > 0.0f) {  // Kaldi framing: power spectrum, fused log-mel output only
+    if constexpr (SPEC_OUT) {
+      return SED_ERR_BAD_ARG;
+    } else {
+      if (pl->geo == 0) return launch_front<Geo512, false, false, true>(pl, p, B, s);
+      if (pl->geo == 1) return launch_front<Geo1024, false, false, true>(pl, p, B, s);
+      return launch_front<Geo2048, false, false, true>(pl, p, B, s);
+    }
+  }
 #define SED_DISPATCH(GEO)                                                         \
   return mag ? launch_front<GEO, true, SPEC_OUT>(pl, p, B, s) : launch_front<GEO, false, SPEC_OUT>(pl, p, B, s)
   if (pl->geo == 0) { SED_DISPATCH(Geo512); }

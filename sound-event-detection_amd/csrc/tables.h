@@ -16,10 +16,13 @@ constexpr double kPi = 3.14159265358979323846264338327950288;
 
 // Periodic Hann of win_length placed in n_fft samples: centred (librosa pad_center) or left aligned
 // (tf.signal.stft zero-extends the frame at its end).
-inline std::vector<double> build_window(int n_fft, int win_length, bool left_aligned) {
+// symmetric: torch.hann_window(win_length, periodic=False), denominator win_length - 1.
+inline std::vector<double> build_window(int n_fft, int win_length, bool left_aligned, bool symmetric = false) {
   std::vector<double> w(n_fft, 0.0);
   const int off = left_aligned ? 0 : (n_fft - win_length) / 2;
-  for (int n = 0; n < win_length; ++n) w[off + n] = 0.5 - 0.5 * std::cos(2.0 * kPi * n / win_length);
+  const double den = symmetric ? std::max(1, win_length - 1) : win_length;
+  for (int n = 0; n < win_length; ++n) w[off + n] = 0.5 - 0.5 * std::cos(2.0 * kPi * n / den);
+  if (symmetric && win_length == 1) w[off] = 1.0;
   return w;
 }
 
@@ -99,6 +102,28 @@ inline std::vector<float> mel_htk_tf(int sr, int n_fft, int n_mels, double fmin,
       const double lower = (mel - e[m]) / (e[m + 1] - e[m]);
       const double upper = (e[m + 2] - mel) / (e[m + 2] - e[m + 1]);
       w[(size_t)k * n_mels + m] = (float)std::max(0.0, std::min(lower, upper));
+    }
+  }
+  return w;
+}
+
+// torchaudio.compliance.kaldi.get_mel_banks (vtln_warp 1): triangles linear in mel = 1127 ln(1 + f/700) between
+// low_freq and high_freq (<= 0: offset from Nyquist), evaluated at the n_fft/2 bins below Nyquist; the Nyquist row is
+// zero (kaldi.fbank pads the matrix with a zero column).
+inline std::vector<float> mel_kaldi(int sr, int n_fft, int n_mels, double low_freq, double high_freq) {
+  const int F = n_fft / 2 + 1;
+  auto mel = [](double f) { return 1127.0 * std::log(1.0 + f / 700.0); };
+  if (high_freq <= 0.0) high_freq += 0.5 * sr;
+  const double bin_width = (double)sr / n_fft;
+  const double mel_low = mel(low_freq), mel_high = mel(high_freq);
+  const double delta = (mel_high - mel_low) / (n_mels + 1);
+  std::vector<float> w((size_t)F * n_mels, 0.0f);
+  for (int k = 0; k < n_fft / 2; ++k) {
+    const double m = mel(bin_width * k);
+    for (int b = 0; b < n_mels; ++b) {
+      const double left = mel_low + b * delta, center = left + delta, right = left + 2.0 * delta;
+      const double up = (m - left) / (center - left), down = (right - m) / (right - center);
+      w[(size_t)k * n_mels + b] = (float)std::max(0.0, std::min(up, down));
     }
   }
   return w;

@@ -22,10 +22,11 @@ SED_OK = 0
 SED_ERR_BAD_ARG, SED_ERR_UNSUPPORTED_NFFT, SED_ERR_CAPACITY, SED_ERR_SHORT_INPUT, SED_ERR_WRONG_DEVICE = -1, -2, -3, -4, -5
 PAD_NONE, PAD_CONSTANT, PAD_REFLECT = 0, 1, 2
 SPEC_MAGNITUDE, SPEC_POWER = 1, 2
-MEL_SLANEY, MEL_HTK_TF = 0, 1
-LOG_NONE, LOG_DB10, LOG_LN = 0, 1, 2
+MEL_SLANEY, MEL_HTK_TF, MEL_KALDI = 0, 1, 2
+LOG_NONE, LOG_DB10, LOG_LN, LOG_LN_FLOOR = 0, 1, 2, 3
 PCM_F32, PCM_I16 = 0, 1
 WIN_CENTER, WIN_LEFT = 0, 1
+WINDOW_HANN_PERIODIC, WINDOW_HANN_SYMMETRIC = 0, 1
 SMOOTH_NONE, SMOOTH_MEDIAN3, SMOOTH_GAUSS25 = 0, 1, 2
 
 
@@ -39,6 +40,7 @@ class FrontendCfg(C.Structure):
         ("fmin", C.c_float), ("fmax", C.c_float),
         ("log_kind", C.c_int32), ("amin", C.c_float), ("ref", C.c_float), ("ln_offset", C.c_float),
         ("pcm_kind", C.c_int32), ("pcm_divisor", C.c_float),
+        ("window_kind", C.c_int32), ("remove_dc", C.c_int32), ("preemphasis", C.c_float),
     ]
 
 
@@ -50,6 +52,7 @@ SIGNATURES = {
     "sed_status_string": (C.c_char_p, [C.c_int]),
     "sed_mel_filterbank": (C.c_int, [_i32, _i32, _i32, _i32, _f32, _f32, _vp]),
     "sed_hann_window": (C.c_int, [_i32, _i32, _i32, _vp]),
+    "sed_window": (C.c_int, [_i32, _i32, _i32, _i32, _vp]),
     "sed_plan_create": (C.c_int, [C.POINTER(FrontendCfg), C.POINTER(_vp)]),
     "sed_plan_destroy": (None, [_vp]),
     "sed_plan_num_frames": (_i64, [_vp, _i64]),

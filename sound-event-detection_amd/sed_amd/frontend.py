@@ -49,12 +49,16 @@ class FrontendConfig:
     ln_offset: float = 0.0
     pcm_kind: int = L.PCM_F32
     pcm_divisor: float = 32767.0
+    window_kind: int = L.WINDOW_HANN_PERIODIC
+    remove_dc: int = 0
+    preemphasis: float = 0.0
 
     def to_c(self) -> L.FrontendCfg:
         return L.FrontendCfg(self.sample_rate, self.n_fft, self.win_length, self.hop, int(self.center), self.pad_mode,
                              self.win_align, self.tail_min_samples, self.tail_hop_samples, self.spectrum,
                              self.mel_kind, self.n_mels, self.fmin, self.fmax, self.log_kind, self.amin, self.ref,
-                             self.ln_offset, self.pcm_kind, self.pcm_divisor)
+                             self.ln_offset, self.pcm_kind, self.pcm_divisor, self.window_kind, self.remove_dc,
+                             self.preemphasis)
 
     @property
     def n_bins(self) -> int:
@@ -86,6 +90,23 @@ class FrontendConfig:
                               fmax=float(sr // 2), log_kind=L.LOG_DB10, amin=1e-10, ref=1.0, **kw)
 
 
+    @staticmethod
+    def kaldi_fbank(sample_frequency=16000.0, num_mel_bins=128, frame_length=25.0, frame_shift=10.0, low_freq=20.0,
+                    high_freq=0.0, preemphasis_coefficient=0.97, remove_dc_offset=True, **kw):
+        """torchaudio.compliance.kaldi.fbank as called at external/audio_mamba/src/dataloader.py:133-134
+        (htk_compat=True, use_energy=False, window_type='hanning', dither=0, snip_edges, power spectrum, log)."""
+        sr = int(round(sample_frequency))
+        win = int(sr * frame_length * 0.001)
+        hop = int(sr * frame_shift * 0.001)
+        n_fft = 1 << max(1, (win - 1).bit_length())
+        fmax = float(high_freq) if high_freq > 0 else float(high_freq) + 0.5 * sr
+        return FrontendConfig(sr, n_fft, win, hop, False, L.PAD_NONE, L.WIN_LEFT, spectrum=L.SPEC_POWER,
+                              mel_kind=L.MEL_KALDI, n_mels=num_mel_bins, fmin=float(low_freq), fmax=fmax,
+                              log_kind=L.LOG_LN_FLOOR, amin=float(np.finfo(np.float32).eps),
+                              window_kind=L.WINDOW_HANN_SYMMETRIC, remove_dc=int(bool(remove_dc_offset)),
+                              preemphasis=float(preemphasis_coefficient), **kw)
+
+
 def mel_filterbank(cfg: FrontendConfig) -> torch.Tensor:
     """(F, n_mels) fp32 CPU tensor: the matrix logmel_extractor.melW holds (host-side table builder)."""
     out = np.empty((cfg.n_bins, cfg.n_mels), dtype=np.float32)
@@ -94,9 +115,10 @@ def mel_filterbank(cfg: FrontendConfig) -> torch.Tensor:
     return torch.from_numpy(out)
 
 
-def hann_window(n_fft: int, win_length: int, win_align: int = L.WIN_CENTER) -> torch.Tensor:
+def hann_window(n_fft: int, win_length: int, win_align: int = L.WIN_CENTER,
+                window_kind: int = L.WINDOW_HANN_PERIODIC) -> torch.Tensor:
     out = np.empty(n_fft, dtype=np.float32)
-    L.check(L.lib.sed_hann_window(n_fft, win_length, win_align, out.ctypes.data), "sed_hann_window")
+    L.check(L.lib.sed_window(window_kind, n_fft, win_length, win_align, out.ctypes.data), "sed_window")
     return torch.from_numpy(out)
 
 
@@ -433,6 +455,45 @@ def yamnet_log_mel(waveform):
     if squeeze:
         return lm[0], patches[0]
     return lm, patches
+
+
+def kaldi_fbank(waveform, sample_frequency=16000.0, num_mel_bins=23, frame_length=25.0, frame_shift=10.0,
+                low_freq=20.0, high_freq=0.0, preemphasis_coefficient=0.97, remove_dc_offset=True, dither=0.0,
+                use_energy=False, htk_compat=False, window_type="hanning", **unsupported):
+    """torchaudio.compliance.kaldi.fbank for the options the reference uses (external/audio_mamba/src/
+    dataloader.py:133-134): waveform (1, L) -> (T, num_mel_bins); a batch (B, L) with B > 1 -> (B, T, num_mel_bins).
+
+    T = 1 + (L - window) // shift (snip_edges); every other option of torchaudio's function must keep its default.
+    """
+    if unsupported or dither != 0.0 or use_energy or window_type != "hanning":
+        raise ValueError("kaldi_fbank supports dither=0, use_energy=False, window_type='hanning' and default "
+                         f"values elsewhere (got {sorted(unsupported)})")
+    x, _ = _as_cuda_batch(waveform)
+    cfg = FrontendConfig.kaldi_fbank(sample_frequency, num_mel_bins, frame_length, frame_shift, low_freq, high_freq,
+                                     preemphasis_coefficient, remove_dc_offset)
+    if x.shape[1] < cfg.win_length:
+        return x.new_empty((0, num_mel_bins)) if x.shape[0] == 1 else x.new_empty((x.shape[0], 0, num_mel_bins))
+    out = _functional(cfg, "btm")(x)
+    return out[0] if x.shape[0] == 1 else out
+
+
+def wav2fbank(waveform, sr, melbins=128, target_length=1024, fshift=10, norm_mean=None, norm_std=None):
+    """AudiosetDataset._wav2fbank + the normalisation of __getitem__ (external/audio_mamba/src/dataloader.py:94-152,
+    219-221) for one clip (1, L) or a batch (B, L): mean removal, Kaldi fbank, zero-pad / cut to target_length frames,
+    then (x - norm_mean) / (2 norm_std) when both are given.  Returns (B, target_length, melbins)."""
+    x, _ = _as_cuda_batch(waveform)
+    x = x - x.mean(dim=1, keepdim=True)
+    fb = kaldi_fbank(x, sample_frequency=sr, num_mel_bins=melbins, frame_shift=fshift, htk_compat=True)
+    if fb.dim() == 2:
+        fb = fb[None]
+    n = fb.shape[1]
+    if n < target_length:
+        fb = torch.nn.functional.pad(fb, (0, 0, 0, target_length - n))
+    else:
+        fb = fb[:, :target_length]
+    if norm_mean is not None and norm_std is not None:
+        fb = (fb - norm_mean) / (norm_std * 2)
+    return fb
 
 
 def extract_mbe(_y, _sr, _nfft, _nb_mel, _hop_len):
