@@ -197,6 +197,19 @@ int sed_merge_runs(const int32_t* runs, const int32_t* counts, int64_t n_groups,
                    const double* time_table, int32_t table_len, double gap, int32_t* out_runs,
                    int32_t* out_counts, void* stream);
 
+/* ---- detector -> classifier hand-off ----------------------------------------------------------------- */
+
+/* Cuts event e = samples [start, end) of stream ev_stream[e] out of the resident PCM batch into row e of a
+ * zero-padded fp32 batch, without going through files.  Replaces cut_events_from_audio (src/utils/cut_audio.py:13-53:
+ * sf.read, audio_array[int(start_sec*sr):int(end_sec*sr)], sf.write per event) as called at main.py:123-127,136-138.
+ * ev_start/ev_end: the caller's int(sec*sr) values; they follow numpy's slice rules (negative counts from the end,
+ * then both are clipped to [0, L]).  pcm: [n_streams] clips of L samples, fp32 or int16 (divided by pcm_divisor,
+ * 32768 for soundfile's int16 decoding).  out: fp32 [n_events][cap]; out_len int32 [n_events] = slice length, of
+ * which the first min(len, cap) samples are copied.  All pointers are device pointers. */
+int sed_cut_events(const void* pcm, int32_t pcm_kind, float pcm_divisor, int64_t n_streams, int64_t L,
+                   int64_t pcm_stride, const int32_t* ev_stream, const int64_t* ev_start, const int64_t* ev_end,
+                   int64_t n_events, float* out, int64_t cap, int32_t* out_len, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -34,3 +34,12 @@ for name, cfg, x in cases:
     byts = x.shape[0] * x.shape[1] * esz + y.numel() * 4
     hours = x.shape[0] * x.shape[1] / cfg.sample_rate / 3600
     print(f"{name:28s} {us:8.1f} us  {byts/us/1e6:7.2f} TB/s algorithmic  {hours/(us*1e-6):9.0f} audio-h/s  frames {y.shape[1]}")
+
+# detector -> classifier hand-off: 2048 events of 1..3 s cut out of 256 x 10 s @ 32 kHz
+rng = np.random.default_rng(0)
+pcm = (torch.randn(256, 320000, generator=g) * 0.1).to(dev)
+ev = [(int(rng.integers(256)), float(a), float(a + d)) for a, d in zip(rng.uniform(0, 7, 2048), rng.uniform(1, 3, 2048))]
+clips, lens = sed_amd.cut_events(pcm, 32000, ev, cap=96000)
+us = timeit(lambda: sed_amd.cut_events(pcm, 32000, ev, cap=96000))
+moved = int(lens.clamp(max=96000).sum().item()) * 4 + clips.numel() * 4
+print(f"{'cut_events 2048 x <=3 s':28s} {us:8.1f} us  {moved/us/1e6:7.2f} TB/s (slice reads + padded batch writes; includes the host-side index upload)")

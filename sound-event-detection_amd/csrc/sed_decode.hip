@@ -338,3 +338,68 @@ extern "C" int sed_merge_runs(const int32_t* runs, const int32_t* counts, int64_
                      nullptr, out_runs, out_counts);
   return hip_status(hipGetLastError());
 }
+
+// ---- detector -> classifier hand-off: event ranges of the resident PCM batch into a zero-padded batch ----------
+// grid.y = event, grid.x x 256 threads x 4 samples cover the row; every output sample is written exactly once
+// (16-byte stores; the source is only sample-aligned, so it is read element by element through L1/L2).
+template <typename T>
+__global__ void __launch_bounds__(256) cut_events_kernel(const T* pcm, float div, int64_t n_streams, int64_t L,
+                                                         int64_t pcm_stride, const int32_t* ev_stream,
+                                                         const int64_t* ev_start, const int64_t* ev_end, float* out,
+                                                         int64_t cap, int32_t* out_len) {
+  const int64_t e = blockIdx.y;
+  int64_t a = ev_start[e], b = ev_end[e];
+  if (a < 0) a += L;
+  if (b < 0) b += L;
+  a = a < 0 ? 0 : (a > L ? L : a);
+  b = b < 0 ? 0 : (b > L ? L : b);
+  const int sidx = ev_stream[e];
+  const bool ok = sidx >= 0 && sidx < n_streams;
+  const int64_t len = (ok && b > a) ? b - a : 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) out_len[e] = (int32_t)(len > INT32_MAX ? INT32_MAX : len);
+  const T* src = pcm + (ok ? (int64_t)sidx * pcm_stride + a : 0);
+  float* dst = out + e * cap;
+  const bool vec = (cap % 4 == 0) && (((uintptr_t)out) % 16 == 0);
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < cap; i += (int64_t)gridDim.x * 1024) {
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t j = i + k;
+      float x = 0.0f;
+      if (j < len) x = std::is_same<T, float>::value ? (float)src[j] : (float)src[j] / div;
+      v[k] = x;
+    }
+    if (vec) {
+      *reinterpret_cast<float4*>(dst + i) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (i + k < cap) dst[i + k] = v[k];
+    }
+  }
+}
+
+extern "C" int sed_cut_events(const void* pcm, int32_t pcm_kind, float pcm_divisor, int64_t n_streams, int64_t L,
+                              int64_t pcm_stride, const int32_t* ev_stream, const int64_t* ev_start,
+                              const int64_t* ev_end, int64_t n_events, float* out, int64_t cap, int32_t* out_len,
+                              void* stream) {
+  if (n_streams < 0 || L < 0 || pcm_stride < L || n_events < 0 || cap < 0) return SED_ERR_BAD_ARG;
+  if (pcm_kind != SED_PCM_F32 && pcm_kind != SED_PCM_I16) return SED_ERR_BAD_ARG;
+  if (pcm_kind == SED_PCM_I16 && !(pcm_divisor > 0.0f)) return SED_ERR_BAD_ARG;
+  if (n_events == 0) return SED_OK;
+  if (!ev_stream || !ev_start || !ev_end || !out_len || (cap > 0 && !out) || (n_streams > 0 && L > 0 && !pcm))
+    return SED_ERR_BAD_ARG;
+  const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>((cap + 1023) / 1024, 64));
+  for (int64_t e0 = 0; e0 < n_events; e0 += 65535) {  // grid.y limit
+    const dim3 grid(gx, (unsigned)std::min<int64_t>(65535, n_events - e0));
+    if (pcm_kind == SED_PCM_F32)
+      hipLaunchKernelGGL(cut_events_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)pcm, 1.0f,
+                         n_streams, L, pcm_stride, ev_stream + e0, ev_start + e0, ev_end + e0, out + e0 * cap, cap,
+                         out_len + e0);
+    else
+      hipLaunchKernelGGL(cut_events_kernel<int16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const int16_t*)pcm,
+                         pcm_divisor, n_streams, L, pcm_stride, ev_stream + e0, ev_start + e0, ev_end + e0,
+                         out + e0 * cap, cap, out_len + e0);
+  }
+  return hip_status(hipGetLastError());
+}

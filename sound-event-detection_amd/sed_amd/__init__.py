@@ -5,6 +5,7 @@ from .frontend import (FrontendConfig, LogMelFrontend, LogmelFilterBank, Spectro
 from .decode import (decode_predictions, decode_probabilities, detect_onsets_offsets, detect_onsets_offsets_batch,
                      get_classification_label, get_events, get_events_from_batch, merge_close_events,
                      merge_close_events_batch, predict_events, predict_events_batch, process_json_file)
+from .handoff import cut_events, cut_events_from_audio
 from . import sharding
 
 __version__ = _lib.lib.sed_version().decode()

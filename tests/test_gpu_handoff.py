@@ -1,0 +1,69 @@
+"""GPU parity of the detector -> classifier hand-off against numpy slicing (what cut_events_from_audio writes,
+src/utils/cut_audio.py:33-41): bit exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import frontend as of
+
+pytestmark = pytest.mark.gpu
+
+
+def _expected(x, sr, events, cap, div=None):
+    out = np.zeros((len(events), cap), np.float32)
+    lens = np.zeros(len(events), np.int32)
+    for i, (s, a, b) in enumerate(events):
+        sl = x[s][int(a * sr):int(b * sr)]
+        if div is not None:
+            sl = (sl.astype(np.float32) / np.float32(div)).astype(np.float32)
+        lens[i] = len(sl)
+        out[i, :min(len(sl), cap)] = sl[:cap]
+    return out, lens
+
+
+def test_cut_events_matches_numpy_slices():
+    import sed_amd
+    dev = torch.device("cuda", 0)
+    sr = 44100
+    x = of.synth_batch(4, 5 * sr + 17, sr, first=90)
+    events = [(0, 0.0, 0.48), (1, 0.96, 2.4), (3, 4.8, 6.0), (2, 1.234, 1.2345), (2, 3.0, 2.0), (0, 0.333, 4.999),
+              (1, 7.0, 8.0), (3, -0.5, 0.25), (0, 4.9, 5.5)]
+    clips, lens = sed_amd.cut_events(torch.from_numpy(x).to(dev), sr, events)
+    want, wl = _expected(x, sr, events, clips.shape[1])
+    assert clips.shape[1] % 4 == 0 and np.array_equal(lens.cpu().numpy(), wl)
+    assert np.array_equal(clips.cpu().numpy(), want)
+    small, lens2 = sed_amd.cut_events(torch.from_numpy(x).to(dev), sr, events, cap=1001)     # truncation, odd capacity
+    want2, _ = _expected(x, sr, events, 1001)
+    assert np.array_equal(small.cpu().numpy(), want2) and np.array_equal(lens2.cpu().numpy(), wl)
+    s16 = of.f32_to_pcm16(x)
+    c16, l16 = sed_amd.cut_events(torch.from_numpy(s16).to(dev), sr, events)
+    w16, _ = _expected(s16, sr, events, c16.shape[1], div=32768.0)
+    assert np.array_equal(c16.cpu().numpy(), w16) and np.array_equal(l16.cpu().numpy(), wl)
+    e0, l0 = sed_amd.cut_events(torch.from_numpy(x).to(dev), sr, [])
+    assert e0.shape[0] == 0 and l0.shape == (0,)
+    with pytest.raises(RuntimeError):
+        sed_amd.cut_events(torch.from_numpy(x), sr, events)
+
+
+def test_cut_events_from_audio_names_and_rows():
+    import sed_amd
+    dev = torch.device("cuda", 0)
+    sr = 32000
+    x = of.synth_batch(2, 10 * sr, sr, first=95)
+    events_list = {"a/soundscape_01.wav": [{"event_onset": 0.48, "event_offset": 1.92, "label": "siren"},
+                                            {"event_onset": 5.76, "event_offset": 6.24, "label": "siren"}],
+                   "b/soundscape_02.wav": [{"event_onset": 2.4, "event_offset": 10.08, "label": "cough"}]}
+    clips, lens, upd = sed_amd.cut_events_from_audio(torch.from_numpy(x).to(dev), sr,
+                                                     ["a/soundscape_01.wav", "b/soundscape_02.wav"], events_list)
+    assert [e["extracted_audio_filename"] for e in upd["a/soundscape_01.wav"]] == \
+        ["soundscape_01_0.48_1.92.wav", "soundscape_01_5.76_6.24.wav"]
+    assert upd["b/soundscape_02.wav"][0]["extracted_audio_filename"] == "soundscape_02_2.40_10.08.wav"
+    assert upd["b/soundscape_02.wav"][0]["label"] == "cough" and "clip_index" not in events_list["b/soundscape_02.wav"][0]
+    for name, s in (("a/soundscape_01.wav", 0), ("b/soundscape_02.wav", 1)):
+        for ev in upd[name]:
+            sl = x[s][int(ev["event_onset"] * sr):int(ev["event_offset"] * sr)]
+            row = clips[ev["clip_index"]].cpu().numpy()
+            assert lens[ev["clip_index"]].item() == len(sl)
+            assert np.array_equal(row[:len(sl)], sl) and not row[len(sl):].any()
+    fe = sed_amd.LogMelFrontend(sed_amd.FrontendConfig.htsat())
+    assert fe(clips).shape[0] == 3                                        # the rows feed the classifier front-end as is
