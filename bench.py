@@ -98,9 +98,7 @@ def main():
         y = fe(x)
         if i is not None:
             k_events[i][1].record()
-        runs, counts = D.threshold_runs(det, 0.5, "median3")
-        mruns, mcounts = D.merge_runs(runs, counts, table, 0.6)
-        buf = torch.cat([mcounts[..., None], mruns.flatten(-2)], -1)
+        buf = D.threshold_merge_runs(det, 0.5, table, 0.6, "median3")   # (streams, classes, 1 + 2*cap): count, runs
         if world > 1:
             # (the gloo rehearsal gathers host copies: gloo's device-tensor path stalls after a few async gathers)
             src = buf if args.backend == "nccl" else buf.cpu()

@@ -197,6 +197,14 @@ int sed_merge_runs(const int32_t* runs, const int32_t* counts, int64_t n_groups,
                    const double* time_table, int32_t table_len, double gap, int32_t* out_runs,
                    int32_t* out_counts, void* stream);
 
+/* sed_threshold_runs followed by sed_merge_runs in one launch (the detector decode of yamnet_train.py:55-71, then
+ * the gap merge of merge_events.py:36-55, per stream and class): packed int32 [B*C][1 + 2*cap] holds, per trace,
+ * the merged count and then its (start, end) frame pairs.  cap >= T/2 + 1 and cap <= 256 (the raw runs of a trace
+ * stay in LDS), else SED_ERR_CAPACITY. */
+int sed_threshold_merge_runs(const float* probs, int64_t B, int64_t T, int64_t C, float threshold, int32_t smoothing,
+                             const double* time_table, int32_t table_len, double gap, int32_t* packed, int32_t cap,
+                             void* stream);
+
 /* ---- detector -> classifier hand-off ----------------------------------------------------------------- */
 
 /* Cuts event e = samples [start, end) of stream ev_stream[e] out of the resident PCM batch into row e of a

@@ -45,16 +45,9 @@ __device__ __forceinline__ float smoothed(const float* x, int64_t stride, int t,
 }
 
 // ---- threshold runs -------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) threshold_runs_kernel(const float* probs, int64_t n_traces, int T, int C,
-                                                             float thr, int smoothing, int32_t* runs, int32_t* counts,
-                                                             int cap) {
-  const int lane = threadIdx.x & 63;
-  const int64_t trace = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (trace >= n_traces) return;
-  const int64_t b = trace / C;
-  const int c = (int)(trace - b * C);
-  const float* x = probs + b * (int64_t)T * C + c;
-  int32_t* out = runs + trace * (int64_t)cap * 2;
+// One wavefront, one trace: writes (start, end) frame pairs to out[2 r], out[2 r + 1] and returns the number of runs.
+__device__ __forceinline__ int threshold_runs_wave(const float* x, int T, int C, float thr, int smoothing, int32_t* out,
+                                                   int cap, int lane) {
   int n_runs = 0, n_ends = 0, carry = 0;
   for (int t0 = 0; t0 <= T; t0 += 64) {  // frame T is a virtual inactive frame that closes a trailing run
     const int t = t0 + lane;
@@ -75,6 +68,19 @@ __global__ void __launch_bounds__(256) threshold_runs_kernel(const float* probs,
     n_ends += __popcll(em);
     carry = (int)(word >> 63);
   }
+  return n_runs;
+}
+
+__global__ void __launch_bounds__(256) threshold_runs_kernel(const float* probs, int64_t n_traces, int T, int C,
+                                                             float thr, int smoothing, int32_t* runs, int32_t* counts,
+                                                             int cap) {
+  const int lane = threadIdx.x & 63;
+  const int64_t trace = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (trace >= n_traces) return;
+  const int64_t b = trace / C;
+  const int c = (int)(trace - b * C);
+  const int n_runs = threshold_runs_wave(probs + b * (int64_t)T * C + c, T, C, thr, smoothing,
+                                         runs + trace * (int64_t)cap * 2, cap, lane);
   if (lane == 0) counts[trace] = n_runs;
 }
 
@@ -180,19 +186,13 @@ __global__ void __launch_bounds__(256) argmax_hist_kernel(const float* probs, in
 // the events that open a new merged event (onsets ascend and fl(a - b) is monotone in b, so an offset from
 // an already closed merged event can only be the maximum when the current one would break anyway);
 // a merged event's offset is the maximum offset between two consecutive marks.
+// One wavefront, one group of n onset-sorted events starting at element `base` of the input arrays (runs: frame
+// pairs looked up in `table`; otherwise fp64 onsets/offsets); merged events go to element out_base + r of the output
+// arrays.  Returns the number of merged events.
 template <bool FROM_RUNS>
-__global__ void __launch_bounds__(256) merge_kernel(const double* onsets, const double* offsets,
-                                                    const int32_t* group_start, const int32_t* runs,
-                                                    const int32_t* counts, int cap, const double* table, int table_len,
-                                                    int64_t n_groups, double gap, double* out_on, double* out_off,
-                                                    int32_t* out_runs, int32_t* out_counts) {
-  const int lane = threadIdx.x & 63;
-  const int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (g >= n_groups) return;
-  int64_t base;
-  int n;
-  if (FROM_RUNS) { base = g * (int64_t)cap; n = min(counts[g], cap); }
-  else { base = group_start[g]; n = group_start[g + 1] - group_start[g]; }
+__device__ __forceinline__ int merge_wave(const double* onsets, const double* offsets, const int32_t* runs, int64_t base,
+                                          int n, const double* table, int table_len, double gap, double* out_on,
+                                          double* out_off, int32_t* out_runs, int64_t out_base, int lane) {
   int n_out = 0;
   double carry_pmax = -INFINITY;   // max of all offsets seen so far in the group
   double carry_smax = -INFINITY;   // max offset of the merged event that is still open
@@ -242,11 +242,11 @@ __global__ void __launch_bounds__(256) merge_kernel(const double* onsets, const 
     if (head) {
       const int r = n_out + __popcll(hm & lanemask_lt(lane));
       if (FROM_RUNS) {
-        out_runs[(base + r) * 2] = on_k;
-        if (r >= 1) out_runs[(base + r - 1) * 2 + 1] = prev_sidx;
+        out_runs[(out_base + r) * 2] = on_k;
+        if (r >= 1) out_runs[(out_base + r - 1) * 2 + 1] = prev_sidx;
       } else {
-        out_on[base + r] = on;
-        if (r >= 1) out_off[base + r - 1] = prev_smax;
+        out_on[out_base + r] = on;
+        if (r >= 1) out_off[out_base + r - 1] = prev_smax;
       }
     }
     n_out += __popcll(hm);
@@ -255,14 +255,53 @@ __global__ void __launch_bounds__(256) merge_kernel(const double* onsets, const 
     carry_smax = __shfl(smax, last);
     carry_sidx = __shfl(sidx, last);
   }
-  if (lane == 0) {
-    if (n_out >= 1) {
-      if (FROM_RUNS) out_runs[(base + n_out - 1) * 2 + 1] = carry_sidx;
-      else out_off[base + n_out - 1] = carry_smax;
-    }
-    out_counts[g] = n_out;
+  if (lane == 0 && n_out >= 1) {
+    if (FROM_RUNS) out_runs[(out_base + n_out - 1) * 2 + 1] = carry_sidx;
+    else out_off[out_base + n_out - 1] = carry_smax;
   }
+  return n_out;
 }
+
+template <bool FROM_RUNS>
+__global__ void __launch_bounds__(256) merge_kernel(const double* onsets, const double* offsets,
+                                                    const int32_t* group_start, const int32_t* runs,
+                                                    const int32_t* counts, int cap, const double* table, int table_len,
+                                                    int64_t n_groups, double gap, double* out_on, double* out_off,
+                                                    int32_t* out_runs, int32_t* out_counts) {
+  const int lane = threadIdx.x & 63;
+  const int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (g >= n_groups) return;
+  int64_t base;
+  int n;
+  if (FROM_RUNS) { base = g * (int64_t)cap; n = min(counts[g], cap); }
+  else { base = group_start[g]; n = group_start[g + 1] - group_start[g]; }
+  const int n_out = merge_wave<FROM_RUNS>(onsets, offsets, runs, base, n, table, table_len, gap, out_on, out_off,
+                                          out_runs, base, lane);
+  if (lane == 0) out_counts[g] = n_out;
+}
+
+// Threshold -> runs -> gap merge -> packed record in one launch: the raw runs of a trace stay in LDS.
+// packed[trace] = (count, start_0, end_0, start_1, end_1, ...), 1 + 2*cap ints per trace.
+constexpr int kFusedCap = 256;  // raw runs per trace the LDS buffer holds (T <= 2*kFusedCap - 2)
+__global__ void __launch_bounds__(256) threshold_merge_kernel(const float* probs, int64_t n_traces, int T, int C,
+                                                              float thr, int smoothing, const double* table,
+                                                              int table_len, double gap, int32_t* packed, int cap) {
+  __shared__ int32_t raw[4][2 * kFusedCap];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t trace = (int64_t)blockIdx.x * 4 + w;
+  if (trace >= n_traces) return;
+  const int64_t b = trace / C;
+  const int c = (int)(trace - b * C);
+  const int n = threshold_runs_wave(probs + b * (int64_t)T * C + c, T, C, thr, smoothing, raw[w], cap, lane);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  int32_t* rec = packed + trace * (int64_t)(1 + 2 * cap);
+  const int n_out = merge_wave<true>(nullptr, nullptr, raw[w], 0, min(n, cap), table, table_len, gap, nullptr, nullptr,
+                                     rec + 1, 0, lane);
+  if (lane == 0) rec[0] = n_out;
+}
+
 
 }  // namespace sed
 
@@ -336,6 +375,19 @@ extern "C" int sed_merge_runs(const int32_t* runs, const int32_t* counts, int64_
   hipLaunchKernelGGL(merge_kernel<true>, dim3(blocks_for(n_groups)), dim3(256), 0, (hipStream_t)stream, nullptr,
                      nullptr, nullptr, runs, counts, (int)cap, time_table, (int)table_len, n_groups, gap, nullptr,
                      nullptr, out_runs, out_counts);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int sed_threshold_merge_runs(const float* probs, int64_t B, int64_t T, int64_t C, float threshold,
+                                        int32_t smoothing, const double* time_table, int32_t table_len, double gap,
+                                        int32_t* packed, int32_t cap, void* stream) {
+  if (B < 0 || T < 0 || C < 0 || cap < 1 || smoothing < 0 || smoothing > 2 || table_len < 1) return SED_ERR_BAD_ARG;
+  if (T >= INT32_MAX - 64 || C > INT32_MAX || B * C > (int64_t)INT32_MAX * 4) return SED_ERR_BAD_ARG;
+  if (cap > kFusedCap || T / 2 + 1 > cap) return SED_ERR_CAPACITY;  // every raw run must fit the LDS buffer
+  if (B * C == 0) return SED_OK;
+  if (!packed || !time_table || (T > 0 && !probs)) return SED_ERR_BAD_ARG;
+  hipLaunchKernelGGL(threshold_merge_kernel, dim3(blocks_for(B * C)), dim3(256), 0, (hipStream_t)stream, probs, B * C,
+                     (int)T, (int)C, threshold, (int)smoothing, time_table, (int)table_len, gap, packed, (int)cap);
   return hip_status(hipGetLastError());
 }
 

@@ -109,6 +109,20 @@ def merge_runs(runs: torch.Tensor, counts: torch.Tensor, time_table: torch.Tenso
     return out_runs, out_counts
 
 
+def threshold_merge_runs(probs: torch.Tensor, threshold: float, time_table: torch.Tensor, gap: float, smoothing=None):
+    """threshold_runs + merge_runs in one launch: probs (B, T, C) -> packed int32 (B, C, 1 + 2*cap), cap = T//2 + 1;
+    packed[b, c, 0] = merged count, then (start, end) frame pairs.  T <= 510 (longer traces: the two-step path)."""
+    B, T, Cn = probs.shape
+    cap = T // 2 + 1
+    packed = torch.empty((B, Cn, 1 + 2 * cap), dtype=torch.int32, device=probs.device)
+    with torch.cuda.device(probs.device):
+        L.check(L.lib.sed_threshold_merge_runs(probs.data_ptr(), B, T, Cn, float(np.float32(threshold)),
+                                               _SMOOTH[smoothing], time_table.data_ptr(), time_table.numel(),
+                                               float(gap), packed.data_ptr(), cap, L.stream_ptr(probs.device)),
+                "sed_threshold_merge_runs")
+    return packed
+
+
 def merge_event_groups(onsets: torch.Tensor, offsets: torch.Tensor, group_start: torch.Tensor, gap: float):
     """fp64 onsets/offsets (n,), group_start int32 (G+1,) -> merged onsets, offsets (n,), counts (G,)."""
     G = group_start.numel() - 1

@@ -217,3 +217,29 @@ def test_frame_run_merge_matches_time_merge():
                          key=lambda t: t[0])
             want = [(e["event_onset"], e["event_offset"], e["event_label"]) for e in od.merge_close_events(events[f], gap)]
             assert sorted(got) == sorted(want), (gap, f)
+
+
+def test_fused_threshold_merge_equals_two_launches():
+    """sed_threshold_merge_runs against sed_threshold_runs + sed_merge_runs: identical counts and frame pairs."""
+    from sed_amd import decode as D
+    rng = np.random.default_rng(77)
+    dev = torch.device("cuda", 0)
+    for (B, T, C), smooth, gap, step in (((256, 20, 1), "median3", 0.6, 0.48), ((33, 41, 6), "median3", 0.3, 0.48),
+                                         ((16, 500, 5), "gauss", 1.0, 1024 / 44100), ((5, 1, 2), None, 0.6, 0.48),
+                                         ((7, 64, 3), None, 0.6, 0.1), ((3, 129, 4), "median3", 0.0, 0.25)):
+        probs = torch.from_numpy(rng.random((B, T, C)).astype(np.float32)).to(dev)
+        probs[0] = 1.0                                                  # one fully active stream
+        probs[-1] = 0.0                                                 # one silent stream
+        table = torch.tensor([round(k * step, 3) for k in range(T + 2)], dtype=torch.float64, device=dev)
+        runs, counts = D.threshold_runs(probs, 0.5, smooth)
+        mruns, mcounts = D.merge_runs(runs, counts, table, gap)
+        packed = D.threshold_merge_runs(probs, 0.5, table, gap, smooth).cpu().numpy()
+        mruns, mcounts = mruns.cpu().numpy(), mcounts.cpu().numpy()
+        assert packed.shape == (B, C, 1 + 2 * (T // 2 + 1))
+        assert np.array_equal(packed[..., 0], mcounts)
+        for b in range(B):
+            for c in range(C):
+                n = mcounts[b, c]
+                assert np.array_equal(packed[b, c, 1:1 + 2 * n].reshape(n, 2), mruns[b, c, :n]), (B, T, C, b, c)
+    with pytest.raises(ValueError):
+        D.threshold_merge_runs(torch.zeros((1, 600, 1), device=dev), 0.5, table, 0.6)   # beyond the LDS capacity
