@@ -218,6 +218,15 @@ int sed_cut_events(const void* pcm, int32_t pcm_kind, float pcm_divisor, int64_t
                    int64_t pcm_stride, const int32_t* ev_stream, const int64_t* ev_start, const int64_t* ev_end,
                    int64_t n_events, float* out, int64_t cap, int32_t* out_len, void* stream);
 
+/* ---- HTS-AT glue behind the front-end ------------------------------------------------------------------ */
+
+/* reshape_wav2img (external/hts_audio_transformer/model/htsat.py:729-744) for mel_bins == spec_size / freq_ratio:
+ * bicubic interpolation (align_corners=True) of logmel fp32 [B][T][M] along time to target_T = spec_size*freq_ratio
+ * frames (copied when T == target_T), then img fp32 [B][1][freq_ratio*M][target_T/freq_ratio] with
+ * img[b][0][r*M + f][u] = y[b][r*(target_T/freq_ratio) + u][f].  T <= target_T, target_T % freq_ratio == 0. */
+int sed_htsat_wav2img(const float* logmel, int64_t B, int64_t T, int64_t M, int64_t target_T, int32_t freq_ratio,
+                      float* img, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

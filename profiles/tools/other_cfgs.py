@@ -43,3 +43,9 @@ clips, lens = sed_amd.cut_events(pcm, 32000, ev, cap=96000)
 us = timeit(lambda: sed_amd.cut_events(pcm, 32000, ev, cap=96000))
 moved = int(lens.clamp(max=96000).sum().item()) * 4 + clips.numel() * 4
 print(f"{'cut_events 2048 x <=3 s':28s} {us:8.1f} us  {moved/us/1e6:7.2f} TB/s (slice reads + padded batch writes; includes the host-side index upload)")
+
+# HTS-AT glue: (256, 1, 1001, 64) log-mel -> (256, 1, 256, 256) image
+lm = torch.randn(256, 1, 1001, 64, device=dev)
+img = sed_amd.reshape_wav2img(lm)
+us = timeit(lambda: sed_amd.reshape_wav2img(lm))
+print(f"{'reshape_wav2img 256 clips':28s} {us:8.1f} us  {(lm.numel() + img.numel()) * 4 / us / 1e6:7.2f} TB/s (read log-mel + write image)")

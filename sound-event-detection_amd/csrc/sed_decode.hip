@@ -455,3 +455,62 @@ extern "C" int sed_cut_events(const void* pcm, int32_t pcm_kind, float pcm_divis
   }
   return hip_status(hipGetLastError());
 }
+
+// ---- HTS-AT glue: log-mel (B, T, M) -> square image (B, 1, freq_ratio*M, target_T/freq_ratio) -----------------
+// reshape_wav2img: bicubic interpolation along time to target_T frames (torch's upsample_bicubic2d with
+// align_corners=True, A = -0.75, border indices clamped; the mel axis keeps its size, so its taps are (0,1,0,0)),
+// then the time axis is folded freq_ratio times under the mel axis: img[b][r*M + f][u] = y[b][r*(target_T/ratio) + u][f].
+__device__ __forceinline__ float cubic1(float x, float A) { return ((A + 2.0f) * x - (A + 3.0f)) * x * x + 1.0f; }
+__device__ __forceinline__ float cubic2(float x, float A) { return ((A * x - 5.0f * A) * x + 8.0f * A) * x - 4.0f * A; }
+
+__global__ void __launch_bounds__(256) wav2img_kernel(const float* x, int T, int M, int target_T, int ratio, float scale,
+                                                      float* img) {
+  extern __shared__ float rows[];  // input frames [n_rows][M + 1]
+  const int seg = target_T / ratio;             // image width
+  const int tiles = (seg + 63) / 64;
+  const int tile = blockIdx.x % tiles, r = blockIdx.x / tiles, b = blockIdx.y;
+  const int u0 = tile * 64, t0 = r * seg + u0;  // first output frame of this tile
+  const int n_out = min(64, seg - u0);
+  const int lo = max(0, (int)floorf(scale * (float)t0) - 1);
+  const int hi = min(T - 1, (int)floorf(scale * (float)(t0 + n_out - 1)) + 2);
+  const int n_rows = hi - lo + 1, pitch = M + 1;
+  const float* src = x + ((int64_t)b * T + lo) * M;
+  for (int i = threadIdx.x; i < n_rows * M; i += 256) rows[(i / M) * pitch + i % M] = src[i];
+  __syncthreads();
+  const float A = -0.75f;
+  for (int i = threadIdx.x; i < n_out * M; i += 256) {
+    const int u = i % n_out, f = i / n_out;     // consecutive threads -> consecutive image columns
+    const int t = t0 + u;
+    float v;
+    if (T == target_T) {
+      v = rows[(t - lo) * pitch + f];
+    } else {
+      const float real = scale * (float)t;
+      const float fl = floorf(real);
+      const int k = (int)fl;
+      const float tt = real - fl;
+      const float c0 = cubic2(tt + 1.0f, A), c1 = cubic1(tt, A), c2 = cubic1(1.0f - tt, A), c3 = cubic2(2.0f - tt, A);
+      const float v0 = rows[(min(max(k - 1, 0), T - 1) - lo) * pitch + f];
+      const float v1 = rows[(min(max(k, 0), T - 1) - lo) * pitch + f];
+      const float v2 = rows[(min(max(k + 1, 0), T - 1) - lo) * pitch + f];
+      const float v3 = rows[(min(max(k + 2, 0), T - 1) - lo) * pitch + f];
+      v = v0 * c0 + v1 * c1 + v2 * c2 + v3 * c3;
+    }
+    img[(((int64_t)b * ratio + r) * M + f) * seg + u0 + u] = v;
+  }
+}
+
+extern "C" int sed_htsat_wav2img(const float* logmel, int64_t B, int64_t T, int64_t M, int64_t target_T,
+                                 int32_t freq_ratio, float* img, void* stream) {
+  if (B < 0 || T < 1 || M < 1 || M > 512 || freq_ratio < 1 || target_T < T || target_T % freq_ratio != 0)
+    return SED_ERR_BAD_ARG;
+  if (B > 65535 || target_T > INT32_MAX / 2) return SED_ERR_BAD_ARG;
+  if (B == 0) return SED_OK;
+  if (!logmel || !img) return SED_ERR_BAD_ARG;
+  const float scale = target_T > 1 ? (float)(T - 1) / (float)(target_T - 1) : 0.0f;
+  const int seg = (int)(target_T / freq_ratio), tiles = (seg + 63) / 64;
+  const size_t lds = (size_t)(64 + 6) * (M + 1) * sizeof(float);
+  hipLaunchKernelGGL(wav2img_kernel, dim3((unsigned)(tiles * freq_ratio), (unsigned)B), dim3(256), lds,
+                     (hipStream_t)stream, logmel, (int)T, (int)M, (int)target_T, (int)freq_ratio, scale, img);
+  return hip_status(hipGetLastError());
+}

@@ -496,6 +496,28 @@ def wav2fbank(waveform, sr, melbins=128, target_length=1024, fshift=10, norm_mea
     return fb
 
 
+def reshape_wav2img(x: torch.Tensor, spec_size: int = 256, freq_ratio: int = None) -> torch.Tensor:
+    """HTSAT_Swin_Transformer.reshape_wav2img (external/hts_audio_transformer/model/htsat.py:729-744):
+    x (B, 1, T, F) log-mel -> (B, 1, spec_size, spec_size) for F == spec_size // freq_ratio (freq_ratio defaults to
+    spec_size // F as at htsat.py:444).  T < spec_size*freq_ratio is interpolated (bicubic, align_corners=True)."""
+    _require_cuda(x, "reshape_wav2img")
+    if x.dim() != 4 or x.shape[1] != 1:
+        raise RuntimeError(f"expected a (batch, 1, time, mel) tensor, got shape {tuple(x.shape)}")
+    B, _, T, F = x.shape
+    if freq_ratio is None:
+        freq_ratio = spec_size // F
+    target_T, target_F = spec_size * freq_ratio, spec_size // freq_ratio
+    assert T <= target_T and F <= target_F, "the wav size should less than or equal to the swin input size"
+    if F != target_F:
+        raise ValueError("reshape_wav2img: the mel axis must already have spec_size // freq_ratio bins")
+    x = x.to(torch.float32).contiguous()
+    img = torch.empty((B, 1, freq_ratio * F, target_T // freq_ratio), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        L.check(L.lib.sed_htsat_wav2img(x.data_ptr(), B, T, F, target_T, freq_ratio, img.data_ptr(),
+                                        L.stream_ptr(x.device)), "sed_htsat_wav2img")
+    return img
+
+
 def extract_mbe(_y, _sr, _nfft, _nb_mel, _hop_len):
     """Log mel-band energies, (n_mels, T) (or (B, n_mels, T) for a batch); numpy in -> numpy out."""
     x, squeeze = _as_cuda_batch(_y)

@@ -239,6 +239,27 @@ def test_kaldi_fbank_and_aum_wav2fbank():
         sed_amd.kaldi_fbank(torch.zeros(1, 16000), sample_frequency=16000, use_energy=True)
 
 
+def test_reshape_wav2img_against_restatement():
+    """HTS-AT glue (htsat.py:729-744): HIP vs the fp32 restatement (itself pinned against torch on the CPU)."""
+    import sed_amd
+    dev = _dev()
+    rng = np.random.default_rng(4)
+    for (B, T, F, spec, ratio) in ((3, 1001, 64, 256, 4), (2, 1024, 64, 256, 4), (3, 37, 4, 16, 4), (1, 5, 8, 8, 1),
+                                   (2, 400, 128, 256, 2)):
+        x = (rng.standard_normal((B, 1, T, F)) * 20 - 40).astype(np.float32)
+        got = sed_amd.reshape_wav2img(torch.from_numpy(x).to(dev), spec, ratio)
+        want = of.htsat_reshape_wav2img(x, spec, ratio)
+        assert got.shape == want.shape == (B, 1, spec, spec)
+        assert np.max(np.abs(got.cpu().numpy() - want)) <= 1e-6 * np.max(np.abs(x)) * 2, (T, F)
+        if T == spec * ratio:
+            assert np.array_equal(got.cpu().numpy(), want)
+    fe = sed_amd.LogMelFrontend(sed_amd.FrontendConfig.htsat())
+    y = fe(torch.from_numpy(of.synth_batch(2, 320000, 32000, first=5)).to(dev))     # (2, 1, 1001, 64)
+    assert sed_amd.reshape_wav2img(y).shape == (2, 1, 256, 256)
+    with pytest.raises(AssertionError):
+        sed_amd.reshape_wav2img(torch.zeros(1, 1, 1025, 64, device=dev))
+
+
 def test_state_dict_and_install_on_reference_shaped_model():
     import sed_amd
     from torch import nn

@@ -66,3 +66,22 @@ def test_pcm16_convention():
     f = of.pcm16_to_f32(s)
     assert f.dtype == np.float32
     assert np.array_equal(f, (s.astype(np.float32) / np.float32(32767.0)))   # fp32 division gives the same bits
+
+
+def test_reshape_wav2img_restatement_matches_torch_interpolate():
+    """The reference calls torch.nn.functional.interpolate(mode='bicubic', align_corners=True) and folds the time axis
+    (htsat.py:729-744); torch is importable here, so the restatement is pinned against the very function."""
+    import torch
+    rng = np.random.default_rng(3)
+    for (B, T, F, spec, ratio) in ((2, 1001, 64, 256, 4), (1, 1024, 64, 256, 4), (3, 37, 4, 16, 4), (1, 5, 8, 8, 1)):
+        x = (rng.standard_normal((B, 1, T, F)) * 20 - 40).astype(np.float32)
+        got = of.htsat_reshape_wav2img(x, spec, ratio)
+        y = torch.from_numpy(x)
+        if T < spec * ratio:
+            y = torch.nn.functional.interpolate(y, (spec * ratio, F), mode="bicubic", align_corners=True)
+        y = y.permute(0, 1, 3, 2).contiguous()
+        y = y.reshape(B, 1, F, ratio, spec).permute(0, 1, 3, 2, 4).contiguous().reshape(B, 1, F * ratio, spec)
+        assert got.shape == tuple(y.shape)
+        assert np.max(np.abs(got - y.numpy())) <= 1e-6 * np.max(np.abs(x)) * 2      # a few ulp of the largest value
+        if T == spec * ratio:
+            assert np.array_equal(got, y.numpy())
