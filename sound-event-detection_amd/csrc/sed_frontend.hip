@@ -203,13 +203,17 @@ __device__ __forceinline__ void mel_mfma_4frames(const FrontParams& p, const int
     const float* ap = mela + ((size_t)s * (U + 1) * 64 + lane) * 4;
     v4 acc = v4{0.0f, 0.0f, 0.0f, 0.0f};
     for (int u0 = 0; u0 < U; u0 += kMelBurst) {
-      // one burst of LDS reads for kMelBurst steps of 4 bins (steps past the end read the all-zero weights), then
-      // the instructions, two steps per (wave-uniform) test
+      // one burst of LDS reads for up to kMelBurst steps of 4 bins, then the instructions, two steps per
+      // (wave-uniform) test
       v4 a[kMelBurst], b[kMelBurst];
-      static_for<0, kMelBurst>([&](auto Uf) {
-        constexpr int k = decltype(Uf)::value;
-        a[k] = ld4(ap + 256 * min(u0 + k, U));
-        b[k] = ld4(bp + 4 * min(u0 + k, U - 1));
+      static_for<0, kMelBurst / 2>([&](auto Pf) {
+        constexpr int k = 2 * decltype(Pf)::value;
+        if (u0 + k < U) {  // wave-uniform: pairs of steps past the end are not fetched at all
+          a[k] = ld4(ap + 256 * (u0 + k));
+          b[k] = ld4(bp + 4 * (u0 + k));
+          a[k + 1] = ld4(ap + 256 * (u0 + k + 1));  // u0 + k + 1 == U reads the all-zero weights
+          b[k + 1] = ld4(bp + 4 * min(u0 + k + 1, U - 1));
+        }
       });
       SED_SCHED_FENCE();  // the whole burst is in flight before the first instruction waits for its operands
       static_for<0, kMelBurst / 2>([&](auto Pf) {
