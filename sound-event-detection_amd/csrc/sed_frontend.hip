@@ -244,13 +244,16 @@ __device__ __forceinline__ v4 mel_gather_log(const FrontParams& p, const int32_t
   const int npos = g >> 16;
   const float* first = part + (g & 0xffff);
   v4 sum = v4{0.0f, 0.0f, 0.0f, 0.0f};
-  for (int i0 = 0; i0 < p.mel_maxpos; i0 += 4) {
-    v4 v[4];
-    static_for<0, 4>([&](auto If) {
+  for (int i0 = 0; i0 < p.mel_maxpos; i0 += 8) {
+    // exactly as many reads as the widest quad has positions (wave-uniform tests); lanes whose quad has fewer read
+    // a block of zeros
+    v4 v[8];
+    static_for<0, 8>([&](auto If) {
       constexpr int i = decltype(If)::value;
-      v[i] = ld4((i0 + i < npos) ? first + (i0 + i) * kPartStride : zero4);
+      v[i] = v4{0.0f, 0.0f, 0.0f, 0.0f};
+      if (i0 + i < p.mel_maxpos) v[i] = ld4((i0 + i < npos) ? first + (i0 + i) * kPartStride : zero4);
     });
-    sum += (v[0] + v[1]) + (v[2] + v[3]);
+    sum += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
   }
   v4 val = sum;
   if (p.log_kind == SED_LOG_DB10) {
