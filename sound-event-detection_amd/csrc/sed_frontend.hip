@@ -5,8 +5,9 @@
 //   workgroup  : WAVES wavefronts, one workgroup per CU, tables in LDS for the whole launch; after the
 //                table load there is no workgroup barrier: every wavefront streams on its own
 //   wavefront  : owns "chunks" = runs of consecutive frames of one clip and walks them FPW frames at a
-//                time.  Its LDS region holds the PCM span of the current FPW frames; the n_fft-hop samples
-//                shared with the next FPW frames stay in LDS, so every sample is fetched once per chunk
+//                time.  The PCM span of the FPW frames is copied into the wavefront's LDS region (LDS-DMA for
+//                aligned fp32 clips, issued one group ahead), which then serves as exchange buffer, power rows and
+//                partial-sum area of the same group
 //   per frame  : LPF lanes; see fft_core.h for the lane decomposition
 //   mel        : power rows are multiplied by the banded filterbank on the matrix pipe
 //                (v_mfma_f32_4x4x1_16b_f32: 16 blocks x [4 filters x 4 frames] per instruction, exact f32)
@@ -49,7 +50,7 @@ struct FrontParams {
   int32_t T, hop, pad_left, pad_mode, pcm_kind;
   float pcm_div;
   int32_t n_mels, log_kind, affine;
-  float amin, db_offset, ln_offset, inv_n_mels;
+  float amin, db_offset, ln_offset;
   // per-frame conditioning of the Kaldi flavour: DC removal over win_length samples and pre-emphasis
   int32_t remove_dc, win_length, pre_off;  // pre_off: floats from the start of the wave region to its partial-sum scratch
   float preemph, inv_win_length;
@@ -877,7 +878,6 @@ static int front_forward(const sed_plan* pl, const void* pcm, int64_t B, int64_t
   p.pcm_kind = c.pcm_kind;
   p.pcm_div = c.pcm_kind == SED_PCM_I16 ? c.pcm_divisor : 1.0f;
   p.n_mels = c.n_mels;
-  p.inv_n_mels = 1.0f / (float)c.n_mels;
   p.log_kind = c.log_kind;
   p.affine = pl->affine ? 1 : 0;
   p.amin = c.amin;

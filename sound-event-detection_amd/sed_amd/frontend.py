@@ -518,6 +518,18 @@ def reshape_wav2img(x: torch.Tensor, spec_size: int = 256, freq_ratio: int = Non
     return img
 
 
+def long_input_images(x: torch.Tensor, spec_size: int = 256, freq_ratio: int = None):
+    """The evaluation branch of HTSAT_Swin_Transformer.forward for inputs longer than spec_size*freq_ratio frames
+    (external/hts_audio_transformer/model/htsat.py:816-823): crops of (T - 1) // 2 frames every (T - 1) // 4 frames
+    (crop_wav with spe_pos), each through reshape_wav2img.  x (B, 1, T, F) -> list of (B, 1, spec_size, spec_size);
+    the caller averages the model outputs over the list as the reference does (:824-835)."""
+    T = x.shape[2]
+    overlap_size = (T - 1) // 4
+    crop_size = (T - 1) // 2
+    return [reshape_wav2img(x[:, :, pos:pos + crop_size, :], spec_size, freq_ratio)
+            for pos in range(0, T - crop_size - 1, overlap_size)]
+
+
 def extract_mbe(_y, _sr, _nfft, _nb_mel, _hop_len):
     """Log mel-band energies, (n_mels, T) (or (B, n_mels, T) for a batch); numpy in -> numpy out."""
     x, squeeze = _as_cuda_batch(_y)

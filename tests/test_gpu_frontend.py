@@ -258,6 +258,13 @@ def test_reshape_wav2img_against_restatement():
     assert sed_amd.reshape_wav2img(y).shape == (2, 1, 256, 256)
     with pytest.raises(AssertionError):
         sed_amd.reshape_wav2img(torch.zeros(1, 1, 1025, 64, device=dev))
+    xl = (rng.standard_normal((2, 1, 2001, 64)) * 20 - 40).astype(np.float32)        # longer than 1024 frames: htsat.py:816-823
+    imgs = sed_amd.long_input_images(torch.from_numpy(xl).to(dev))
+    pos = list(range(0, 2001 - 1000 - 1, 500))
+    assert len(imgs) == len(pos) == 2
+    for im, p0 in zip(imgs, pos):
+        want = of.htsat_reshape_wav2img(xl[:, :, p0:p0 + 1000], 256, 4)
+        assert np.max(np.abs(im.cpu().numpy() - want)) <= 1e-6 * np.max(np.abs(xl)) * 2
 
 
 def test_state_dict_and_install_on_reference_shaped_model():
