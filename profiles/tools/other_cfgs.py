@@ -49,3 +49,10 @@ lm = torch.randn(256, 1, 1001, 64, device=dev)
 img = sed_amd.reshape_wav2img(lm)
 us = timeit(lambda: sed_amd.reshape_wav2img(lm))
 print(f"{'reshape_wav2img 256 clips':28s} {us:8.1f} us  {(lm.numel() + img.numel()) * 4 / us / 1e6:7.2f} TB/s (read log-mel + write image)")
+
+# BASELINE config 5: 1-hour recordings (4 x 3600 s @ 32 kHz fp32 = 1.84 GB)
+xl = torch.randn(4, 3600 * 32000, device=dev) * 0.1
+fe = sed_amd.LogMelFrontend(sed_amd.FrontendConfig.htsat(), layout="btm")
+y = fe(xl)
+us = timeit(lambda: fe(xl), n=10)
+print(f"{'htsat 4 x 1 h':28s} {us:8.1f} us  {(xl.numel() + y.numel()) * 4 / us / 1e6:7.2f} TB/s algorithmic  {4 / (us * 1e-6):9.0f} audio-h/s  frames {y.shape[1]}")

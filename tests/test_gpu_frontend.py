@@ -335,3 +335,30 @@ def test_full_size_properties_config2():
     ref = of.htsat_logmel(x[250:252].cpu().numpy(), mode="gold")
     near = ref >= ref.max(-1, keepdims=True) - NEAR_DB
     assert np.max(np.abs(y[250:252].cpu().numpy() - ref)[near]) < 1e-3
+
+
+def test_long_form_recording_equals_overlapped_chunks():
+    """BASELINE config 5: a 1-hour recording processed whole equals the same recording processed in 10-minute chunks
+    that overlap by the frames' reach (n_fft/2 samples of context on either side of a chunk's frames): bit exact."""
+    import sed_amd
+    dev = _dev()
+    sr, hop, n_fft = 32000, 320, 1024
+    g = torch.Generator(device=dev).manual_seed(5)
+    n = 3600 * sr
+    x = torch.randn(1, n, generator=g, device=dev) * 0.1
+    fe = sed_amd.LogMelFrontend(sed_amd.FrontendConfig.htsat(), layout="btm")
+    whole = fe(x)
+    assert whole.shape == (1, 1 + n // hop, 64) and torch.isfinite(whole).all()
+    frames_per_chunk = 600 * sr // hop
+    for c in (0, 1, 3, 5):                                              # chunks incl. the first (reflect edge) and the last
+        f0 = c * frames_per_chunk
+        f1 = min(whole.shape[1], f0 + frames_per_chunk)
+        lo = max(0, (f0 - 10) * hop)                                     # ten hops of context (> n_fft/2) on either side,
+        hi = min(n, (f1 - 1 + 10) * hop)                                 # chunk start on the whole recording's frame grid
+        part = fe(x[:, lo:hi].contiguous())
+        first = f0 - lo // hop                                           # frame of `part` that is frame f0 of `whole`
+        got, want = part[:, first:first + (f1 - f0)], whole[:, f0:f1]
+        if hi == n:                                                      # the recording's own last frames reflect the same samples
+            assert torch.equal(got, want), c
+        else:
+            assert torch.equal(got, want), (c, (got != want).nonzero()[:4].tolist())
