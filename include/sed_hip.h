@@ -227,6 +227,20 @@ int sed_cut_events(const void* pcm, int32_t pcm_kind, float pcm_divisor, int64_t
 int sed_htsat_wav2img(const float* logmel, int64_t B, int64_t T, int64_t M, int64_t target_T, int32_t freq_ratio,
                       float* img, void* stream);
 
+/* repeat_wat2img (external/hts_audio_transformer/model/htsat.py:747-760; the enable_repeat_mode branch :783-805):
+ * the same interpolation to target_T frames, then the spec_size frames from cur_pos on, transposed and stacked
+ * `repeats` times (4 in the reference): img fp32 [B][1][repeats*M][spec_size], img[b][0][r*M + f][u] = y[b][cur_pos + u][f].
+ * 0 <= cur_pos, cur_pos + spec_size <= target_T. */
+int sed_htsat_repeat2img(const float* logmel, int64_t B, int64_t T, int64_t M, int64_t target_T, int64_t spec_size,
+                         int64_t cur_pos, int32_t repeats, float* img, void* stream);
+
+/* interpolate(x, ratio) (external/hts_audio_transformer/utils.py:158-172; call at model/htsat.py:707) followed by
+ * pad_framewise_output(., frames_out) (utils.py:175-192): x fp32 [B][T][C] -> out fp32 [B][frames_out][C] with
+ * out[b][t][c] = x[b][min(t / ratio, T - 1)][c].  frames_out = T*ratio is interpolate alone; ratio = 1 is the padding
+ * alone. */
+int sed_framewise_expand(const float* x, int64_t B, int64_t T, int64_t C, int32_t ratio, int64_t frames_out,
+                         float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -391,37 +391,71 @@ def aum_wav2fbank(x, sr, melbins=128, target_length=1024, fshift=10, norm_mean=N
 # pinned against torch.nn.functional.interpolate (the function the reference calls) in tests/test_oracle_frontend.py
 # ----------------------------------------------------------------------------
 
+def _htsat_time_interp(x, target_T):
+    """Bicubic interpolation of (B, 1, T, F) fp32 along T to target_T frames, fp32 arithmetic in the order of torch's
+    upsample_bicubic2d (A = -0.75, align_corners=True, clamped border taps); T == target_T is returned unchanged."""
+    x = np.asarray(x, dtype=np.float32)
+    T = x.shape[2]
+    if T == target_T:
+        return x
+    f32 = np.float32
+    A = f32(-0.75)
+    scale = f32(T - 1) / f32(target_T - 1)
+    real = scale * np.arange(target_T, dtype=np.float32)
+    fl = np.floor(real)
+    k = fl.astype(np.int64)
+    t = (real - fl).astype(np.float32)
+
+    def c1(v):
+        return ((A + f32(2)) * v - (A + f32(3))) * v * v + f32(1)
+
+    def c2(v):
+        return ((A * v - f32(5) * A) * v + f32(8) * A) * v - f32(4) * A
+
+    w = [c2(t + f32(1)), c1(t), c1(f32(1) - t), c2(f32(2) - t)]
+    taps = [x[:, :, np.clip(k + d, 0, T - 1), :] for d in (-1, 0, 1, 2)]
+    y = taps[0] * w[0][None, None, :, None]
+    for i in (1, 2, 3):
+        y = y + taps[i] * w[i][None, None, :, None]
+    return y.astype(np.float32)
+
+
 def htsat_reshape_wav2img(x, spec_size=256, freq_ratio=4):
-    """x (B, 1, T, F) fp32, F == spec_size // freq_ratio -> (B, 1, spec_size, spec_size); fp32 arithmetic in the order
-    of torch's upsample_bicubic2d (A = -0.75, align_corners=True, clamped border taps)."""
+    """external/hts_audio_transformer/model/htsat.py:729-744.  x (B, 1, T, F) fp32, F == spec_size // freq_ratio ->
+    (B, 1, spec_size, spec_size)."""
     x = np.asarray(x, dtype=np.float32)
     B, C, T, F = x.shape
     target_T = spec_size * freq_ratio
     assert C == 1 and T <= target_T and F == spec_size // freq_ratio
-    if T < target_T:
-        f32 = np.float32
-        A = f32(-0.75)
-        scale = f32(T - 1) / f32(target_T - 1)
-        real = scale * np.arange(target_T, dtype=np.float32)
-        fl = np.floor(real)
-        k = fl.astype(np.int64)
-        t = (real - fl).astype(np.float32)
-
-        def c1(v):
-            return ((A + f32(2)) * v - (A + f32(3))) * v * v + f32(1)
-
-        def c2(v):
-            return ((A * v - f32(5) * A) * v + f32(8) * A) * v - f32(4) * A
-
-        w = [c2(t + f32(1)), c1(t), c1(f32(1) - t), c2(f32(2) - t)]
-        taps = [x[:, :, np.clip(k + d, 0, T - 1), :] for d in (-1, 0, 1, 2)]
-        y = taps[0] * w[0][None, None, :, None]
-        for i in (1, 2, 3):
-            y = y + taps[i] * w[i][None, None, :, None]
-        x = y.astype(np.float32)
+    x = _htsat_time_interp(x, target_T)
     x = x.transpose(0, 1, 3, 2)
     x = x.reshape(B, C, F, freq_ratio, target_T // freq_ratio).transpose(0, 1, 3, 2, 4)
     return np.ascontiguousarray(x.reshape(B, C, F * freq_ratio, target_T // freq_ratio))
+
+
+def htsat_repeat_wat2img(x, cur_pos, spec_size=256, freq_ratio=4):
+    """external/hts_audio_transformer/model/htsat.py:747-760.  x (B, 1, T, F) -> (B, 1, 4 F, spec_size)."""
+    x = np.asarray(x, dtype=np.float32)
+    B, C, T, F = x.shape
+    target_T = spec_size * freq_ratio
+    assert C == 1 and T <= target_T and F == spec_size // freq_ratio
+    x = _htsat_time_interp(x, target_T).transpose(0, 1, 3, 2)
+    x = x[:, :, :, cur_pos:cur_pos + spec_size]
+    return np.ascontiguousarray(np.tile(x, (1, 1, 4, 1)))
+
+
+def htsat_interpolate(x, ratio):
+    """external/hts_audio_transformer/utils.py:158-172: (B, T, C) -> (B, T * ratio, C)."""
+    x = np.asarray(x)
+    B, T, C = x.shape
+    return np.ascontiguousarray(np.broadcast_to(x[:, :, None, :], (B, T, ratio, C)).reshape(B, T * ratio, C))
+
+
+def htsat_pad_framewise_output(x, frames_num):
+    """external/hts_audio_transformer/utils.py:175-192: pad along time with the last frame."""
+    x = np.asarray(x)
+    pad = np.repeat(x[:, -1:, :], frames_num - x.shape[1], axis=1)
+    return np.concatenate([x, pad], axis=1)
 
 
 def synth_clip(clip_idx: int, n_samples: int, sr: int) -> np.ndarray:

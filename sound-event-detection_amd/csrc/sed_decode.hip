@@ -460,16 +460,17 @@ extern "C" int sed_cut_events(const void* pcm, int32_t pcm_kind, float pcm_divis
 // reshape_wav2img: bicubic interpolation along time to target_T frames (torch's upsample_bicubic2d with
 // align_corners=True, A = -0.75, border indices clamped; the mel axis keeps its size, so its taps are (0,1,0,0)),
 // then the time axis is folded freq_ratio times under the mel axis: img[b][r*M + f][u] = y[b][r*(target_T/ratio) + u][f].
+// repeat_wat2img is the same kernel with every band r showing the same window: img[b][r*M + f][u] = y[b][cur_pos + u][f].
+// In general band r shows the interpolated frames col0 + r*col_step + [0, seg).
 __device__ __forceinline__ float cubic1(float x, float A) { return ((A + 2.0f) * x - (A + 3.0f)) * x * x + 1.0f; }
 __device__ __forceinline__ float cubic2(float x, float A) { return ((A * x - 5.0f * A) * x + 8.0f * A) * x - 4.0f * A; }
 
-__global__ void __launch_bounds__(256) wav2img_kernel(const float* x, int T, int M, int target_T, int ratio, float scale,
-                                                      float* img) {
+__global__ void __launch_bounds__(256) wav2img_kernel(const float* x, int T, int M, int target_T, int ratio, int seg,
+                                                      int col0, int col_step, float scale, float* img) {
   extern __shared__ float rows[];  // input frames [n_rows][M + 1]
-  const int seg = target_T / ratio;             // image width
   const int tiles = (seg + 63) / 64;
   const int tile = blockIdx.x % tiles, r = blockIdx.x / tiles, b = blockIdx.y;
-  const int u0 = tile * 64, t0 = r * seg + u0;  // first output frame of this tile
+  const int u0 = tile * 64, t0 = col0 + r * col_step + u0;  // first interpolated frame of this tile
   const int n_out = min(64, seg - u0);
   const int lo = max(0, (int)floorf(scale * (float)t0) - 1);
   const int hi = min(T - 1, (int)floorf(scale * (float)(t0 + n_out - 1)) + 2);
@@ -511,6 +512,46 @@ extern "C" int sed_htsat_wav2img(const float* logmel, int64_t B, int64_t T, int6
   const int seg = (int)(target_T / freq_ratio), tiles = (seg + 63) / 64;
   const size_t lds = (size_t)(64 + 6) * (M + 1) * sizeof(float);
   hipLaunchKernelGGL(wav2img_kernel, dim3((unsigned)(tiles * freq_ratio), (unsigned)B), dim3(256), lds,
-                     (hipStream_t)stream, logmel, (int)T, (int)M, (int)target_T, (int)freq_ratio, scale, img);
+                     (hipStream_t)stream, logmel, (int)T, (int)M, (int)target_T, (int)freq_ratio, seg, 0, seg, scale, img);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int sed_htsat_repeat2img(const float* logmel, int64_t B, int64_t T, int64_t M, int64_t target_T,
+                                    int64_t spec_size, int64_t cur_pos, int32_t repeats, float* img, void* stream) {
+  if (B < 0 || T < 1 || M < 1 || M > 512 || repeats < 1 || target_T < T || spec_size < 1) return SED_ERR_BAD_ARG;
+  if (B > 65535 || target_T > INT32_MAX / 2) return SED_ERR_BAD_ARG;
+  if (cur_pos < 0 || cur_pos + spec_size > target_T) return SED_ERR_BAD_ARG;
+  if (B == 0) return SED_OK;
+  if (!logmel || !img) return SED_ERR_BAD_ARG;
+  const float scale = target_T > 1 ? (float)(T - 1) / (float)(target_T - 1) : 0.0f;
+  const int tiles = (int)((spec_size + 63) / 64);
+  const size_t lds = (size_t)(64 + 6) * (M + 1) * sizeof(float);
+  hipLaunchKernelGGL(wav2img_kernel, dim3((unsigned)(tiles * repeats), (unsigned)B), dim3(256), lds,
+                     (hipStream_t)stream, logmel, (int)T, (int)M, (int)target_T, (int)repeats, (int)spec_size,
+                     (int)cur_pos, 0, scale, img);
+  return hip_status(hipGetLastError());
+}
+
+// ---- framewise output of the detector back on the input's frame grid ------------------------------------------
+// interpolate(x, ratio) followed by pad_framewise_output(., frames_out): out[b][t][c] = x[b][min(t / ratio, T-1)][c].
+__global__ void __launch_bounds__(256) framewise_expand_kernel(const float* x, int64_t T, int64_t C, int ratio,
+                                                               int64_t frames_out, int64_t total, float* out) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t c = i % C, bt = i / C;
+    const int64_t t = bt % frames_out, b = bt / frames_out;
+    const int64_t ts = min(t / ratio, T - 1);
+    out[i] = x[(b * T + ts) * C + c];
+  }
+}
+
+extern "C" int sed_framewise_expand(const float* x, int64_t B, int64_t T, int64_t C, int32_t ratio, int64_t frames_out,
+                                    float* out, void* stream) {
+  if (B < 0 || T < 1 || C < 1 || ratio < 1 || frames_out < 0) return SED_ERR_BAD_ARG;
+  const int64_t total = B * frames_out * C;
+  if (total == 0) return SED_OK;
+  if (!x || !out) return SED_ERR_BAD_ARG;
+  const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 256 * 32);
+  hipLaunchKernelGGL(framewise_expand_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, T, C, (int)ratio,
+                     frames_out, total, out);
   return hip_status(hipGetLastError());
 }

@@ -349,3 +349,39 @@ def get_classification_label(pred_map, class_names: Sequence[str] = tuple(CLASSE
     hist = argmax_histogram(p, drop_last_classes=1).cpu().numpy()
     labels = [class_names[int(np.argmax(h))] for h in hist]
     return labels[0] if single else labels
+
+
+def _framewise_expand(x: torch.Tensor, ratio: int, frames_out: int, what: str) -> torch.Tensor:
+    if not (torch.is_tensor(x) and x.is_cuda):
+        raise RuntimeError(f"{what}: expected a tensor on a ROCm device (this path has no CPU implementation)")
+    if x.dim() != 3:
+        raise ValueError(f"{what}: expected (batch_size, time_steps, classes_num), got shape {tuple(x.shape)}")
+    B, T, C = x.shape
+    if T < 1 or C < 1:
+        raise ValueError(f"{what}: empty time or class axis")
+    x = x.to(torch.float32).contiguous()
+    out = torch.empty((B, frames_out, C), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        L.check(L.lib.sed_framewise_expand(x.data_ptr(), B, T, C, int(ratio), int(frames_out), out.data_ptr(),
+                                           L.stream_ptr(x.device)), "sed_framewise_expand")
+    return out
+
+
+def interpolate(x: torch.Tensor, ratio: int) -> torch.Tensor:
+    """external/hts_audio_transformer/utils.py:158-172: (batch_size, time_steps, classes_num) ->
+    (batch_size, time_steps * ratio, classes_num), every frame repeated `ratio` times."""
+    return _framewise_expand(x, ratio, x.shape[1] * int(ratio), "interpolate")
+
+
+def pad_framewise_output(framewise_output: torch.Tensor, frames_num: int) -> torch.Tensor:
+    """external/hts_audio_transformer/utils.py:175-192: pad along time to frames_num frames with the last frame."""
+    if frames_num < framewise_output.shape[1]:
+        raise RuntimeError("pad_framewise_output: frames_num is smaller than the number of frames")  # torch: negative repeat
+    return _framewise_expand(framewise_output, 1, frames_num, "pad_framewise_output")
+
+
+def interpolate_and_pad(x: torch.Tensor, ratio: int, frames_num: int) -> torch.Tensor:
+    """interpolate then pad_framewise_output in one launch."""
+    if frames_num < x.shape[1] * int(ratio):
+        raise RuntimeError("interpolate_and_pad: frames_num is smaller than time_steps * ratio")
+    return _framewise_expand(x, ratio, frames_num, "interpolate_and_pad")

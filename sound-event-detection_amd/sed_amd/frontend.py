@@ -518,6 +518,48 @@ def reshape_wav2img(x: torch.Tensor, spec_size: int = 256, freq_ratio: int = Non
     return img
 
 
+def repeat_wat2img(x: torch.Tensor, cur_pos: int, spec_size: int = 256, freq_ratio: int = None) -> torch.Tensor:
+    """HTSAT_Swin_Transformer.repeat_wat2img (external/hts_audio_transformer/model/htsat.py:747-760): the interpolated
+    log-mel's frames [cur_pos, cur_pos + spec_size), mel axis first, stacked 4 times: (B, 1, T, F) -> (B, 1, 4F, spec_size)."""
+    _require_cuda(x, "repeat_wat2img")
+    if x.dim() != 4 or x.shape[1] != 1:
+        raise RuntimeError(f"expected a (batch, 1, time, mel) tensor, got shape {tuple(x.shape)}")
+    B, _, T, F = x.shape
+    if freq_ratio is None:
+        freq_ratio = spec_size // F
+    target_T, target_F = spec_size * freq_ratio, spec_size // freq_ratio
+    assert T <= target_T and F <= target_F, "the wav size should less than or equal to the swin input size"
+    if F != target_F:
+        raise ValueError("repeat_wat2img: the mel axis must already have spec_size // freq_ratio bins")
+    cur_pos = int(cur_pos)
+    width = max(0, min(spec_size, target_T - cur_pos))               # a slice past the end is short, as in torch
+    if cur_pos < 0 or width < spec_size:
+        raise ValueError(f"repeat_wat2img: cur_pos {cur_pos} leaves fewer than {spec_size} frames of {target_T}")
+    x = x.to(torch.float32).contiguous()
+    img = torch.empty((B, 1, 4 * F, spec_size), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        L.check(L.lib.sed_htsat_repeat2img(x.data_ptr(), B, T, F, target_T, spec_size, cur_pos, 4, img.data_ptr(),
+                                           L.stream_ptr(x.device)), "sed_htsat_repeat2img")
+    return img
+
+
+def repeat_mode_images(x: torch.Tensor, spec_size: int = 256, freq_ratio: int = None):
+    """The evaluation branch of enable_repeat_mode (external/hts_audio_transformer/model/htsat.py:789-793): one image
+    per cur_pos in range(0, (freq_ratio - 1) * spec_size + 1, spec_size); the caller averages the model outputs."""
+    if freq_ratio is None:
+        freq_ratio = spec_size // x.shape[3]
+    return [repeat_wat2img(x, pos, spec_size, freq_ratio) for pos in range(0, (freq_ratio - 1) * spec_size + 1, spec_size)]
+
+
+def infer_mode_image(x: torch.Tensor, spec_size: int = 256, freq_ratio: int = None) -> torch.Tensor:
+    """The infer_mode branch (external/hts_audio_transformer/model/htsat.py:775-781): the log-mel is tiled along time
+    floor(target_T / T) times, then reshape_wav2img."""
+    if freq_ratio is None:
+        freq_ratio = spec_size // x.shape[3]
+    repeat_ratio = (spec_size * freq_ratio) // x.shape[2]
+    return reshape_wav2img(x.repeat(1, 1, repeat_ratio, 1), spec_size, freq_ratio)
+
+
 def long_input_images(x: torch.Tensor, spec_size: int = 256, freq_ratio: int = None):
     """The evaluation branch of HTSAT_Swin_Transformer.forward for inputs longer than spec_size*freq_ratio frames
     (external/hts_audio_transformer/model/htsat.py:816-823): crops of (T - 1) // 2 frames every (T - 1) // 4 frames

@@ -243,3 +243,31 @@ def test_fused_threshold_merge_equals_two_launches():
                 assert np.array_equal(packed[b, c, 1:1 + 2 * n].reshape(n, 2), mruns[b, c, :n]), (B, T, C, b, c)
     with pytest.raises(ValueError):
         D.threshold_merge_runs(torch.zeros((1, 600, 1), device=dev), 0.5, table, 0.6)   # beyond the LDS capacity
+
+
+def test_framewise_interpolate_and_pad():
+    """interpolate / pad_framewise_output (external/hts_audio_transformer/utils.py:158-192): exact copies."""
+    import sed_amd
+    from oracle import frontend as of
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(12)
+    for (B, T, C, ratio, frames) in ((1, 128, 6, 32, 4096), (3, 7, 6, 32, 250), (2, 31, 5, 1, 40), (4, 1, 3, 8, 8),
+                                     (1, 33, 527, 32, 1056)):
+        p = rng.random((B, T, C)).astype(np.float32)
+        pd = torch.from_numpy(p).to(dev)
+        up = sed_amd.interpolate(pd, ratio)
+        want_up = of.htsat_interpolate(p, ratio)
+        assert up.shape == want_up.shape and np.array_equal(up.cpu().numpy(), want_up)
+        want = of.htsat_pad_framewise_output(want_up, frames)
+        assert np.array_equal(sed_amd.pad_framewise_output(up, frames).cpu().numpy(), want)
+        assert np.array_equal(sed_amd.interpolate_and_pad(pd, ratio, frames).cpu().numpy(), want)
+    with pytest.raises(RuntimeError):
+        sed_amd.pad_framewise_output(up, up.shape[1] - 1)
+    with pytest.raises(RuntimeError):
+        sed_amd.interpolate(torch.zeros(1, 4, 6), 32)                                  # host tensor: no CPU path
+    # the HTS-AT framewise output feeds the combined decoder: expansion then smoothing + argmax runs
+    one_hot = np.zeros((1, 128, 6), np.float32)
+    lab = np.repeat(np.array([5, 3, 5, 1, 5, 0, 5, 2]), 16)
+    one_hot[0, np.arange(128), lab] = 1.0
+    full = sed_amd.interpolate(torch.from_numpy(one_hot).to(dev), 32)
+    assert full.shape == (1, 4096, 6) and torch.equal(full[0, ::32], torch.from_numpy(one_hot[0]).to(dev))

@@ -267,6 +267,31 @@ def test_reshape_wav2img_against_restatement():
         assert np.max(np.abs(im.cpu().numpy() - want)) <= 1e-6 * np.max(np.abs(xl)) * 2
 
 
+def test_repeat_mode_and_infer_mode_images():
+    """enable_repeat_mode (htsat.py:747-760, 789-793) and infer_mode (:775-781) image builders vs the restatement."""
+    import sed_amd
+    dev = _dev()
+    rng = np.random.default_rng(8)
+    for (B, T, F, spec, ratio) in ((2, 1001, 64, 256, 4), (1, 1024, 64, 256, 4), (2, 37, 4, 16, 4)):
+        x = (rng.standard_normal((B, 1, T, F)) * 20 - 40).astype(np.float32)
+        xd = torch.from_numpy(x).to(dev)
+        imgs = sed_amd.repeat_mode_images(xd, spec, ratio)
+        positions = list(range(0, (ratio - 1) * spec + 1, spec))
+        assert len(imgs) == len(positions) == ratio
+        for im, pos in zip(imgs, positions):
+            want = of.htsat_repeat_wat2img(x, pos, spec, ratio)
+            assert im.shape == want.shape == (B, 1, 4 * F, spec)
+            assert np.max(np.abs(im.cpu().numpy() - want)) <= 2e-6 * np.max(np.abs(x)), (T, pos)
+        odd = sed_amd.repeat_wat2img(xd, 3, spec, ratio)                               # any cur_pos, as in training (:785)
+        assert np.max(np.abs(odd.cpu().numpy() - of.htsat_repeat_wat2img(x, 3, spec, ratio))) <= 2e-6 * np.max(np.abs(x))
+    with pytest.raises(ValueError):
+        sed_amd.repeat_wat2img(xd, 16 * 4 - 15, 16, 4)                                 # fewer than spec_size frames left
+    x = (rng.standard_normal((2, 1, 300, 64)) * 20 - 40).astype(np.float32)           # 1024 // 300 = 3 tiles -> 900 frames
+    got = sed_amd.infer_mode_image(torch.from_numpy(x).to(dev))
+    want = of.htsat_reshape_wav2img(np.tile(x, (1, 1, 3, 1)), 256, 4)
+    assert np.max(np.abs(got.cpu().numpy() - want)) <= 2e-6 * np.max(np.abs(x))
+
+
 def test_state_dict_and_install_on_reference_shaped_model():
     import sed_amd
     from torch import nn

@@ -85,3 +85,25 @@ def test_reshape_wav2img_restatement_matches_torch_interpolate():
         assert np.max(np.abs(got - y.numpy())) <= 1e-6 * np.max(np.abs(x)) * 2      # a few ulp of the largest value
         if T == spec * ratio:
             assert np.array_equal(got, y.numpy())
+
+
+def test_repeat_mode_and_framewise_restatements_match_torch():
+    """repeat_wat2img (htsat.py:747-760), interpolate and pad_framewise_output (utils.py:158-192) written with the
+    torch calls the reference makes, against the numpy restatements."""
+    import torch
+    rng = np.random.default_rng(6)
+    for (B, T, F, spec, ratio, pos) in ((2, 1001, 64, 256, 4, 256), (1, 1024, 64, 256, 4, 768), (2, 37, 4, 16, 4, 5)):
+        x = (rng.standard_normal((B, 1, T, F)) * 20 - 40).astype(np.float32)
+        y = torch.from_numpy(x)
+        if T < spec * ratio:
+            y = torch.nn.functional.interpolate(y, (spec * ratio, F), mode="bicubic", align_corners=True)
+        y = y.permute(0, 1, 3, 2).contiguous()[:, :, :, pos:pos + spec].repeat(repeats=(1, 1, 4, 1))
+        got = of.htsat_repeat_wat2img(x, pos, spec, ratio)
+        assert got.shape == tuple(y.shape) == (B, 1, 4 * F, spec)
+        assert np.max(np.abs(got - y.numpy())) <= 2e-6 * np.max(np.abs(x))
+    p = rng.random((3, 7, 6)).astype(np.float32)
+    t = torch.from_numpy(p)
+    up = t[:, :, None, :].repeat(1, 1, 32, 1).reshape(3, 7 * 32, 6)
+    assert np.array_equal(of.htsat_interpolate(p, 32), up.numpy())
+    padded = torch.cat((up, up[:, -1:, :].repeat(1, 250 - up.shape[1], 1)), dim=1)
+    assert np.array_equal(of.htsat_pad_framewise_output(up.numpy(), 250), padded.numpy())
