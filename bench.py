@@ -136,7 +136,11 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    kern_ms = sum(a.elapsed_time(b) for a, b in k_events) / max(1, args.steps)
+    k_ms = sorted(a.elapsed_time(b) for a, b in k_events)
+    kern_ms = sum(k_ms) / max(1, len(k_ms))
+
+    def pct(q):
+        return k_ms[min(len(k_ms) - 1, int(q * len(k_ms)))] if k_ms else None
     hours_per_step = world * B_PER_GPU * CLIP_S / 3600.0
     value = hours_per_step * args.steps / elapsed
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
@@ -159,16 +163,28 @@ def main():
                    "parallelism": f"streams sharded over {world} GPU(s), all-gather of event buffers"},
         "roofline": {"bound": "hbm", "kernel": "stft_mel_kernel<n_fft=1024, power, mel+log>", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms},
+                     "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms,
+                     "kernel_ms_p10_p50_p90": [pct(0.1), pct(0.5), pct(0.9)]},
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle.cpu_baseline import time_htsat_cpu
         sample = x[:8].cpu()
         v, el, n = time_htsat_cpu(sample, budget_s=12.0)
-        res["cpu_baseline"] = {"value": v, "unit": "audio-hours/s", "cores": torch.get_num_threads(), "kind": "port",
+        threads = torch.get_num_threads()
+        torch.set_num_threads(1)
+        v1, el1, n1 = time_htsat_cpu(sample[:2], budget_s=5.0)
+        torch.set_num_threads(threads)
+        model = ""
+        try:
+            with open("/proc/cpuinfo") as f:
+                model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "")
+        except OSError:
+            pass
+        res["cpu_baseline"] = {"value": v, "unit": "audio-hours/s", "cores": threads, "kind": "port",
                                "sample": f"{n} passes over 8 of the 256 clips (10 s each), {el:.1f} s of CPU work, "
-                                         "torchlibrosa formulation (fp32 conv-DFT + mel matmul + 10log10) on torch CPU"}
+                                         "torchlibrosa formulation (fp32 conv-DFT + mel matmul + 10log10) on torch CPU",
+                               "single_thread_value": v1, "host_cpus": os.cpu_count(), "cpu_model": model}
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:

@@ -149,6 +149,11 @@ def test_int16_input_and_exhaustive_conversion():
     y16 = sed_amd.LogMelFrontend(cfg16)(torch.from_numpy(s).to(dev))
     yf = sed_amd.LogMelFrontend(sed_amd.FrontendConfig.htsat())(torch.from_numpy(of.pcm16_to_f32(s)).to(dev))
     assert torch.equal(y16, yf)                                          # identical samples -> identical bits
+    for div in (32768.0, 12345.678, 3.0, 1e-3):                          # soundfile's convention and arbitrary scales
+        cfg = sed_amd.FrontendConfig.htsat(pcm_kind=1, pcm_divisor=div)
+        f = (s.astype(np.float32) / np.float32(div)).astype(np.float32)
+        assert torch.equal(sed_amd.LogMelFrontend(cfg)(torch.from_numpy(s).to(dev)),
+                           sed_amd.LogMelFrontend(sed_amd.FrontendConfig.htsat())(torch.from_numpy(f).to(dev))), div
     with pytest.raises(RuntimeError, match="dtype"):
         sed_amd.LogMelFrontend(cfg16)(torch.zeros(1, 4096, device=dev))
 
