@@ -49,8 +49,6 @@ struct FrontParams {
   int64_t L, pcm_stride, out_stride_b;
   int32_t T, hop, pad_left, pad_mode, pcm_kind;
   float pcm_div;
-  float pcm_rcp;      // 1 / pcm_div rounded to fp32
-  int32_t pcm_div3;   // 1: multiply + two fused steps give the bits of the division for every int16 value (checked on the host)
   int32_t n_mels, log_kind, affine;
   float amin, db_offset, ln_offset;
   // per-frame conditioning of the Kaldi flavour: DC removal over win_length samples and pre-emphasis
@@ -109,15 +107,16 @@ __device__ __forceinline__ float log_epilogue(float acc, int log_kind, float ami
   return acc;
 }
 
+// Flag in FrontParams::pcm_kind: multiply + two fused steps give the bits of the division for every int16 value
+// (checked on the host when the plan is made).
+constexpr int kPcmDiv3 = 0x100;
+
 // int16 sample -> fp32 as the reference does it (x / 32767. in fp32).  For divisors the host has checked over all
 // 65536 sample values, q = x * rcp, then q + (x - q * div) * rcp with fused steps is the correctly rounded quotient:
 // three instructions instead of the ten of an IEEE division.
-__device__ __forceinline__ float pcm16_to_f32(float x, float div, float rcp, bool three_ops) {
-  if (three_ops) {
-    const float q = x * rcp;
-    return __builtin_fmaf(__builtin_fmaf(-q, div, x), rcp, q);
-  }
-  return x / div;
+__device__ __forceinline__ float pcm16_to_f32(float x, float div, float rcp) {
+  const float q = x * rcp;
+  return __builtin_fmaf(__builtin_fmaf(-q, div, x), rcp, q);
 }
 
 // Sample `s` of the virtual padded clip: reflect (index -j -> j, L-1+j -> L-1-j) or zeros outside [0, L).
@@ -151,9 +150,14 @@ struct __attribute__((packed, aligned(2))) i16x4_u { short x, y, z, w; };
 // One wavefront copies `count` samples (multiple of 4) of clip b, starting at padded-clip sample s0, to LDS.
 // The fast path issues its loads in batches of 8 x 4 samples per lane before the first LDS store, with clamped
 // (never predicated) addresses: a load under a divergent branch would be waited for on its own.
+template <bool I16>
 __device__ __forceinline__ void stage_span(const FrontParams& p, float* dst, int64_t b, int64_t s0, int count, int lane) {
-  const bool fast = s0 >= 0 && s0 + count <= p.L;
-  if (fast && p.pcm_kind == SED_PCM_F32) {
+  // (int16 plans whose divisor failed the three-instruction check take the out-of-line path with the IEEE division)
+  bool fast = s0 >= 0 && s0 + count <= p.L;
+  if constexpr (I16) fast = fast && (p.pcm_kind & kPcmDiv3);
+  if (!fast) {
+    stage_span_edges(p.pcm, p.pcm_kind & ~kPcmDiv3, p.pcm_div, p.L, p.pad_mode, b * p.pcm_stride, dst, s0, count, lane);
+  } else if constexpr (!I16) {
     const float* src = (const float*)p.pcm + b * p.pcm_stride + s0;
     for (int base = 0; base < count; base += 8 * 256) {
       f32x4_u v[8];
@@ -165,9 +169,9 @@ __device__ __forceinline__ void stage_span(const FrontParams& p, float* dst, int
         st4(dst + min(base + 256 * decltype(Kf)::value + 4 * lane, count - 4), v4{w.x, w.y, w.z, w.w});
       });
     }
-  } else if (fast) {
+  } else {
     const int16_t* src = (const int16_t*)p.pcm + b * p.pcm_stride + s0;
-    const bool fast3 = p.pcm_div3 != 0;
+    const float rcp = 1.0f / p.pcm_div;  // correctly rounded, as the host's check assumed
     for (int base = 0; base < count; base += 8 * 256) {
       i16x4_u v[8];
       static_for<0, 8>([&](auto Kf) {
@@ -176,12 +180,10 @@ __device__ __forceinline__ void stage_span(const FrontParams& p, float* dst, int
       static_for<0, 8>([&](auto Kf) {
         const i16x4_u w = v[decltype(Kf)::value];
         st4(dst + min(base + 256 * decltype(Kf)::value + 4 * lane, count - 4),
-            v4{pcm16_to_f32((float)w.x, p.pcm_div, p.pcm_rcp, fast3), pcm16_to_f32((float)w.y, p.pcm_div, p.pcm_rcp, fast3),
-               pcm16_to_f32((float)w.z, p.pcm_div, p.pcm_rcp, fast3), pcm16_to_f32((float)w.w, p.pcm_div, p.pcm_rcp, fast3)});
+            v4{pcm16_to_f32((float)w.x, p.pcm_div, rcp), pcm16_to_f32((float)w.y, p.pcm_div, rcp),
+               pcm16_to_f32((float)w.z, p.pcm_div, rcp), pcm16_to_f32((float)w.w, p.pcm_div, rcp)});
       });
     }
-  } else {
-    stage_span_edges(p.pcm, p.pcm_kind, p.pcm_div, p.L, p.pad_mode, b * p.pcm_stride, dst, s0, count, lane);
   }
 }
 
@@ -295,6 +297,7 @@ __device__ __forceinline__ v4 mel_gather_log(const FrontParams& p, const int32_t
 
 // Store of one gather round: 16 bytes per lane, 1 KB contiguous per wavefront (frames are n_mels floats apart).
 __device__ __forceinline__ void mel_store(const FrontParams& p, float* dst, v4 val, int r, int nvalid, int lane) {
+  asm volatile("" : "+v"(lane));  // the per-lane output offset is recomputed here instead of living across the loop
   const int j = lane & 3, m0 = 4 * (16 * r + (lane >> 2));
   if (j < nvalid && m0 < p.n_mels) {
     float* o = dst + j * p.n_mels + m0;
@@ -309,7 +312,7 @@ __device__ __forceinline__ void mel_store(const FrontParams& p, float* dst, v4 v
   }
 }
 
-template <class G, bool MAG, bool SPEC_OUT, bool PRE>
+template <class G, bool MAG, bool SPEC_OUT, bool PRE, bool I16>
 __global__ void __launch_bounds__(G::WAVES * 64) __attribute__((amdgpu_waves_per_eu(G::WAVES / 4, G::WAVES / 4)))
 stft_mel_kernel(const FrontParams p) {
   extern __shared__ __align__(16) float smem[];
@@ -385,10 +388,10 @@ stft_mel_kernel(const FrontParams p) {
       const int64_t s0 = (int64_t)f0 * p.hop - p.pad_left;
       LaneState<G> st;
       if (!staged) {
-        if (p.dma && s0 >= 0 && s0 + p.span <= p.L) {
+        if (!I16 && p.dma && s0 >= 0 && s0 + p.span <= p.L) {
           if (!SED_SKIP(p, 1)) stage_span_dma(p, X, b, s0, lane);
         } else {
-          stage_span(p, X, b, s0, p.span, lane);
+          stage_span<I16>(p, X, b, s0, p.span, lane);
         }
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -451,7 +454,7 @@ stft_mel_kernel(const FrontParams p) {
           if constexpr (g == kGroups - 1) {
             // the power rows are consumed: the next group's span may land on them while the gather runs
             const int64_t s1 = s0 + (int64_t)G::FPW * p.hop;
-            if (p.early && f0 + G::FPW < f_end && s1 >= 0 && s1 + p.span <= p.L && !SED_SKIP(p, 1)) {
+            if (!I16 && p.early && f0 + G::FPW < f_end && s1 >= 0 && s1 + p.span <= p.L && !SED_SKIP(p, 1)) {
               stage_span_dma(p, X, b, s1, lane);
               staged = true;
             }
@@ -834,7 +837,8 @@ static int launch_front(const sed_plan* pl, FrontParams p, int64_t B, hipStream_
   while (waves > 1 && (size_t)(p.off_wave + waves * p.wave_floats) * sizeof(float) > 160 * 1024) --waves;
   const size_t lds_bytes = (size_t)(p.off_wave + waves * p.wave_floats) * sizeof(float);
   if (lds_bytes > 160 * 1024) return SED_ERR_BAD_ARG;
-  auto kern = stft_mel_kernel<G, MAG, SPEC_OUT, PRE>;
+  auto kern = (p.pcm_kind & ~kPcmDiv3) == SED_PCM_I16 ? stft_mel_kernel<G, MAG, SPEC_OUT, PRE, true>
+                                                       : stft_mel_kernel<G, MAG, SPEC_OUT, PRE, false>;
   SED_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds_bytes));
   // chunks: runs of consecutive frames of one clip, one wavefront each
@@ -905,8 +909,7 @@ static int front_forward(const sed_plan* pl, const void* pcm, int64_t B, int64_t
   p.pad_mode = c.center ? c.pad_mode : SED_PAD_NONE;
   p.pcm_kind = c.pcm_kind;
   p.pcm_div = c.pcm_kind == SED_PCM_I16 ? c.pcm_divisor : 1.0f;
-  p.pcm_rcp = 1.0f / p.pcm_div;
-  p.pcm_div3 = pl->pcm_div3 ? 1 : 0;
+  if (pl->pcm_div3) p.pcm_kind |= kPcmDiv3;
   p.n_mels = c.n_mels;
   p.log_kind = c.log_kind;
   p.affine = pl->affine ? 1 : 0;
