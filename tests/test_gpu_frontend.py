@@ -4,6 +4,8 @@ Tolerance (fp32 data path, fp64 gold): |hip - gold| <= 1e-3 in the log-mel domai
 60 dB of its frame's peak; on deeper bins the HIP error must not exceed max(1e-3, 1.5 x the error of the
 reference's own fp32 conv-DFT formulation against the same gold).  Exact-silence frames equal the floor.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -392,3 +394,36 @@ def test_long_form_recording_equals_overlapped_chunks():
             assert torch.equal(got, want), c
         else:
             assert torch.equal(got, want), (c, (got != want).nonzero()[:4].tolist())
+
+
+def test_all_flavours_against_committed_vectors():
+    """Every front-end flavour against tests/golden/frontend_golden.npz (oracle outputs frozen on seeded clips)."""
+    import importlib.util
+    import sed_amd
+    dev = _dev()
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("gen_frontend_golden", os.path.join(here, "gen_frontend_golden.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    vec = np.load(os.path.join(here, "frontend_golden.npz"))
+    db, neper_mag, neper_pow = NEAR_DB, NEAR_DB / 20.0 * np.log(10.0), NEAR_DB / 10.0 * np.log(10.0)
+    for name in gen.CASES:
+        x, sr = gen.inputs(name)
+        xd = torch.from_numpy(x).to(dev)
+        gold, ref32 = vec[f"{name}_gold"], vec[f"{name}_ref32"]
+        if name == "htsat":
+            got, span, axis_last = sed_amd.LogMelFrontend(sed_amd.FrontendConfig.htsat())(xd)[:, 0].cpu().numpy(), db, True
+        elif name == "yamnet":
+            got, span, axis_last = sed_amd.yamnet_log_mel(xd)[0].cpu().numpy(), neper_mag, True
+        elif name == "crnn":
+            got, span, axis_last = sed_amd.extract_mbe(x, 44100, 2048, 40, 1024), neper_mag, False
+        elif name == "db_mel":
+            got = sed_amd.get_mel_spec_db(x, 44100)
+            assert got.shape == gold.shape and np.max(np.abs(got - gold)) < 1e-3, name
+            continue
+        else:
+            got = sed_amd.kaldi_fbank(xd, sample_frequency=sr, num_mel_bins=128, frame_shift=10).cpu().numpy()
+            got, span, axis_last = got.reshape(gold.shape), neper_pow, True
+        if not axis_last:                                                # (B, mel, T) -> mel last for the per-frame peak
+            got, gold, ref32 = got.swapaxes(-1, -2), gold.swapaxes(-1, -2), ref32.swapaxes(-1, -2)
+        _check(got, gold, ref32, span, deep_factor=2.5 if name.startswith("kaldi") else 1.5)

@@ -1,4 +1,6 @@
 """The front-end oracle: shapes, floors, and a cross-check against torch.stft (independent implementation)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -107,3 +109,23 @@ def test_repeat_mode_and_framewise_restatements_match_torch():
     assert np.array_equal(of.htsat_interpolate(p, 32), up.numpy())
     padded = torch.cat((up, up[:, -1:, :].repeat(1, 250 - up.shape[1], 1)), dim=1)
     assert np.array_equal(of.htsat_pad_framewise_output(up.numpy(), 250), padded.numpy())
+
+
+def _frontend_golden():
+    import importlib.util
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("gen_frontend_golden", os.path.join(here, "gen_frontend_golden.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    return gen, np.load(os.path.join(here, "frontend_golden.npz"))
+
+
+def test_oracle_reproduces_committed_frontend_vectors():
+    """The fp64 outputs of every front-end flavour on the seeded clips equal the committed vectors (stored as float32):
+    the oracle cannot change without this test noticing."""
+    gen, gold = _frontend_golden()
+    for name in gen.CASES:
+        got = np.asarray(gen.outputs(name, "gold"), np.float64)
+        want = gold[f"{name}_gold"].astype(np.float64)
+        assert got.shape == want.shape, name
+        assert np.max(np.abs(got - want)) <= 1e-5 + 1e-6 * np.max(np.abs(want)), name     # float32 storage of dB / neper values
