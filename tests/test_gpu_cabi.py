@@ -112,3 +112,41 @@ def test_one_plan_on_two_streams_and_a_side_stream():
     assert np.array_equal(g_[:, 0], w_[:, 0]) and g_[:, 0].max() > 0
     for a, b in zip(g_, w_):                                                     # slots past the count are not written
         assert np.array_equal(a[1:1 + 2 * a[0]], b[1:1 + 2 * b[0]])
+
+
+def test_step_is_capturable_in_a_hip_graph():
+    """The front-end and the fused decode launch make no synchronising or allocating HIP call of their own, so a step
+    can be captured once (torch.cuda.graph = hipGraph on ROCm) and replayed; replays give the eager results."""
+    sed_amd, L = _lib()
+    from sed_amd import decode as D
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(4)
+    fe = sed_amd.LogMelFrontend(sed_amd.FrontendConfig.htsat())
+    x = torch.randn(32, 64000, generator=g, device=dev) * 0.1
+    det = torch.rand(32, 20, 1, generator=g, device=dev)
+    table = torch.tensor([k * 0.48 for k in range(22)], dtype=torch.float64, device=dev)
+
+    def step():
+        return fe(x), D.threshold_merge_runs(det, 0.5, table, 0.6, "median3")
+
+    y0, b0 = step()
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        step()                                                                   # warm-up outside the capture
+    torch.cuda.current_stream(dev).wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        yg, bg = step()
+    for _ in range(3):
+        x.mul_(-1.0)                                                             # new input in the captured buffer
+        graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(yg, y0)                                                   # the power spectrum is even in the sign
+    assert torch.equal(bg[..., 0], b0[..., 0])
+    x2 = torch.randn(32, 64000, generator=g, device=dev) * 0.1
+    want = fe(x2)
+    x.copy_(x2)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(yg, want)
