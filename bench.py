@@ -166,7 +166,7 @@ def main():
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "HTS-AT front-end 32 kHz n_fft=1024 hop=320 64 mel, 256 x 10 s clips per GPU "
-                               "(BASELINE configs[1]) + detector decode of the same streams",
+                               "(BASELINE.json configs[1]) + detector decode of the same streams",
                    "clips_per_gpu": B_PER_GPU, "device_prewarm_s": PREWARM_S, "samples_per_clip": L, "frames_per_clip": T, "pcm": "f32",
                    "parallelism": f"streams sharded over {world} GPU(s), all-gather of event buffers"},
         "roofline": {"bound": "hbm", "kernel": "stft_mel_kernel<n_fft=1024, power, mel+log>", "achieved": achieved,

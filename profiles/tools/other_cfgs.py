@@ -50,7 +50,7 @@ img = sed_amd.reshape_wav2img(lm)
 us = timeit(lambda: sed_amd.reshape_wav2img(lm))
 print(f"{'reshape_wav2img 256 clips':28s} {us:8.1f} us  {(lm.numel() + img.numel()) * 4 / us / 1e6:7.2f} TB/s (read log-mel + write image)")
 
-# BASELINE config 5: 1-hour recordings (4 x 3600 s @ 32 kHz fp32 = 1.84 GB)
+# BASELINE.json configs[4]: 1-hour recordings (4 x 3600 s @ 32 kHz fp32 = 1.84 GB)
 xl = torch.randn(4, 3600 * 32000, device=dev) * 0.1
 fe = sed_amd.LogMelFrontend(sed_amd.FrontendConfig.htsat(), layout="btm")
 y = fe(xl)

@@ -78,7 +78,7 @@ def test_decode_predictions_roundtrip(kat, golden_dir):
 
 
 def test_full_crnn_chain_on_synthetic_probabilities(kat):
-    """D2 + D3 + D4 at BASELINE config 3 size (500 x 862 x 5) against the oracle."""
+    """D2 + D3 + D4 at BASELINE.json configs[2] size (500 x 862 x 5) against the oracle."""
     import sed_amd
     from scipy.ndimage import gaussian_filter1d
     rng = np.random.default_rng(21)
@@ -127,7 +127,7 @@ def test_detect_onsets_offsets_vectors(golden_dir):
 
 
 def test_detect_batch_4096_streams():
-    """BASELINE config 4 size: 4096 concurrent 10 s detector streams (20 patches each)."""
+    """BASELINE.json configs[3] size: 4096 concurrent 10 s detector streams (20 patches each)."""
     import sed_amd
     rng = np.random.default_rng(31)
     p = rng.random((4096, 20), dtype=np.float32)

@@ -342,7 +342,7 @@ def test_state_dict_and_install_on_reference_shaped_model():
 
 
 def test_full_size_properties_config2():
-    """BASELINE config 2 (256 x 10 s @ 32 kHz): size-independent properties instead of a full oracle pass."""
+    """BASELINE.json configs[1] (256 x 10 s @ 32 kHz): size-independent properties instead of a full oracle pass."""
     import sed_amd
     dev = _dev()
     g = torch.Generator(device="cpu").manual_seed(1234)
@@ -370,7 +370,7 @@ def test_full_size_properties_config2():
 
 
 def test_long_form_recording_equals_overlapped_chunks():
-    """BASELINE config 5: a 1-hour recording processed whole equals the same recording processed in 10-minute chunks
+    """BASELINE.json configs[4]: a 1-hour recording processed whole equals the same recording processed in 10-minute chunks
     that overlap by the frames' reach (n_fft/2 samples of context on either side of a chunk's frames): bit exact."""
     import sed_amd
     dev = _dev()
