@@ -241,6 +241,30 @@ int sed_htsat_repeat2img(const float* logmel, int64_t B, int64_t T, int64_t M, i
 int sed_framewise_expand(const float* x, int64_t B, int64_t T, int64_t C, int32_t ratio, int64_t frames_out,
                          float* out, void* stream);
 
+/* ---- sample-rate conversion ahead of the front-end ------------------------------------------------------ */
+
+/* Polyphase resampling with the arithmetic of scipy.signal.resample_poly(x, target_sr/g, orig_sr/g), which is what
+ * librosa.resample(..., res_type='polyphase') runs: same Kaiser(5.0) filter bits, same fp32 accumulation order, so the
+ * output equals scipy's bit for bit on fp32 input.  The reference resamples with librosa's default res_type
+ * (librosa.load(file_path, sr=16000), src/models/yamnet_train.py:46 and src/models/single_stage_yamnet_frame.py:25-27;
+ * librosa.resample(track, ofs, rfs), external/hts_audio_transformer/utils.py:211), i.e. soxr_hq, whose filter lives in
+ * libsoxr: this entry point replaces those calls only when they are given res_type='polyphase'.
+ * Supported: target_sr/g <= 1024 and at most 128 filter coefficients per phase (orig_sr/target_sr up to about 6),
+ * else SED_ERR_BAD_ARG. */
+typedef struct sed_resampler sed_resampler;
+int sed_resampler_create(int32_t orig_sr, int32_t target_sr, sed_resampler** out);
+void sed_resampler_destroy(sed_resampler* r);
+/* ceil(n_in * up / down), the length scipy returns. */
+int64_t sed_resampler_out_len(const sed_resampler* r, int64_t n_in);
+/* up, down, coefficients per phase, the number of leading outputs scipy drops, and (if table_host != NULL) the fp32
+ * coefficient table [up][taps] with table[phase][j] = zero-padded filter[phase + up*j].  Any pointer may be NULL. */
+int sed_resampler_get_filter(const sed_resampler* r, int32_t* up, int32_t* down, int32_t* taps, int32_t* n_pre_remove,
+                             float* table_host);
+/* pcm [B][pcm_stride] fp32 or int16 (SED_PCM_*; int16 samples are divided by pcm_divisor first) -> out fp32
+ * [B][out_stride], sed_resampler_out_len(L) samples per row.  Asynchronous on `stream`. */
+int sed_resampler_forward(const sed_resampler* r, const void* pcm, int32_t pcm_kind, float pcm_divisor, int64_t B,
+                          int64_t L, int64_t pcm_stride, float* out, int64_t out_stride, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

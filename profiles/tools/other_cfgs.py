@@ -56,3 +56,14 @@ fe = sed_amd.LogMelFrontend(sed_amd.FrontendConfig.htsat(), layout="btm")
 y = fe(xl)
 us = timeit(lambda: fe(xl), n=10)
 print(f"{'htsat 4 x 1 h':28s} {us:8.1f} us  {(xl.numel() + y.numel()) * 4 / us / 1e6:7.2f} TB/s algorithmic  {4 / (us * 1e-6):9.0f} audio-h/s  frames {y.shape[1]}")
+
+# sample-rate conversion ahead of the YAMNet front-end: 512 x 10 s, 44.1 kHz -> 16 kHz
+for name, xin in (("resample 44.1k->16k f32 512x10s", torch.randn(512, 441000, device=dev) * 0.1),
+                  ("resample 44.1k->16k i16 512x10s", (torch.randn(512, 441000, device=dev) * 3000).to(torch.int16)),
+                  ("resample 48k->16k f32 512x10s", torch.randn(512, 480000, device=dev) * 0.1)):
+    rs = sed_amd.Resampler(48000 if "48k" in name else 44100, 16000)
+    y = rs(xin)
+    us = timeit(lambda: rs(xin), n=20)
+    moved = xin.numel() * xin.element_size() + y.numel() * 4
+    sr_in = 48000 if "48k" in name else 44100
+    print(f"{name:34s} {us:8.1f} us  {moved / us / 1e6:7.2f} TB/s (read + write)  {xin.shape[0] * xin.shape[1] / sr_in / 3600 / (us * 1e-6):9.0f} audio-h/s")

@@ -74,6 +74,11 @@ SIGNATURES = {
     "sed_htsat_wav2img": (C.c_int, [_vp, _i64, _i64, _i64, _i64, _i32, _vp, _vp]),
     "sed_htsat_repeat2img": (C.c_int, [_vp, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _vp, _vp]),
     "sed_framewise_expand": (C.c_int, [_vp, _i64, _i64, _i64, _i32, _i64, _vp, _vp]),
+    "sed_resampler_create": (C.c_int, [_i32, _i32, C.POINTER(_vp)]),
+    "sed_resampler_destroy": (None, [_vp]),
+    "sed_resampler_out_len": (_i64, [_vp, _i64]),
+    "sed_resampler_get_filter": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), _vp]),
+    "sed_resampler_forward": (C.c_int, [_vp, _vp, _i32, _f32, _i64, _i64, _i64, _vp, _i64, _vp]),
     "sed_cut_events": (C.c_int, [_vp, _i32, _f32, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp]),
 }
 
