@@ -27,45 +27,100 @@ struct ResampleParams {
   const void* pcm;
   float* out;
   const float* table;  // [up][TP]: table[phase][j] = padded filter[phase + up*j], zero beyond the filter
-  int64_t B, L, pcm_stride, out_stride, n_out, tiles;
-  int32_t up, down, n_pre_remove, qstep, stage_count;
+  int64_t B, pcm_stride, out_stride;
+  int32_t L, n_out, tiles, up, down, n_pre_remove, q0, qstep, stage_count, perm, n_iter;
   float div;
 };
 
-template <int TP, typename T>
-__global__ void __launch_bounds__(TP > 64 ? 512 : 1024) resample_kernel(const ResampleParams p) {
-  extern __shared__ float xs[];
+constexpr int kStageRegs = 16;
+
+// Tile = R groups of blockDim.x consecutive outputs.  Thread t owns output o = (t * perm) % blockDim.x of every group
+// (perm is coprime with the group length and chosen on the host so that the lanes of a wavefront spread over the LDS
+// banks): the group length is a multiple of `up`, so the thread meets one filter phase only and keeps its TP
+// coefficients in registers.  The input span of a tile is staged in LDS once; the span of the next tile is fetched
+// into registers while the current one is computed.
+template <int TP, int R, typename T>
+__global__ void __launch_bounds__(512) resample_kernel(const ResampleParams p) {
+  extern __shared__ __align__(16) float lds[];
   const int t = threadIdx.x, NT = blockDim.x;
-  const int64_t tt = ((int64_t)t + p.n_pre_remove) * p.down;
+  float* xs = lds;                   // [stage_count] input span of the tile
+  float* ys = lds + p.stage_count;   // [R][NT] outputs of the tile in natural order
+  const int o = (int)(((int64_t)t * p.perm) % NT);
+  const int64_t tt = ((int64_t)o + p.n_pre_remove) * p.down;
   const int phase = (int)(tt % p.up);
-  const int64_t q_t = tt / p.up;                                          // newest input sample of output t of tile 0
-  const int64_t q_0 = ((int64_t)p.n_pre_remove * p.down) / p.up;          // the same for thread 0
+  const int lo = (int)(tt / p.up) - p.q0;  // oldest input of output o (group 0) within the span
   float c[TP];
 #pragma unroll
-  for (int j = 0; j < TP; ++j) c[j] = p.table[(int64_t)phase * TP + j];
-  const int base = (int)(q_t - q_0) + TP - 1;                             // position of q_t in the staged span
-  for (int64_t work = blockIdx.x; work < p.B * p.tiles; work += gridDim.x) {
-    const int64_t b = work / p.tiles, tile = work - b * p.tiles;
-    const int64_t k_lo = q_0 + tile * p.qstep - (TP - 1);
-    const T* src = (const T*)p.pcm + b * p.pcm_stride;
-    for (int i = t; i < p.stage_count; i += NT) {
-      const int64_t k = k_lo + i;
-      float v = 0.0f;
-      if (k >= 0 && k < p.L) {
-        if constexpr (std::is_same<T, float>::value) v = src[k];
-        else v = (float)src[k] / p.div;
-      }
-      xs[i] = v;
-    }
-    __syncthreads();
-    const int64_t m = tile * NT + t;
-    if (m < p.n_out) {
-      float acc = 0.0f;
+  for (int j = 0; j < TP; ++j) c[j] = p.table[phase * TP + j];
+  T pre[kStageRegs];
+  const int total = (int)p.B * p.tiles;
+  auto fetch = [&](int work) {
+    const int b = work / p.tiles, tile = work - b * p.tiles;
+    const int k_lo = p.q0 + tile * (R * p.qstep) - (TP - 1);
+    const T* src = (const T*)p.pcm + (int64_t)b * p.pcm_stride;
 #pragma unroll
-      for (int j = TP - 1; j >= 0; --j) acc = __fadd_rn(acc, __fmul_rn(xs[base - j], c[j]));
-      p.out[b * p.out_stride + m] = acc;
-    }
+    for (int n = 0; n < kStageRegs; ++n)
+      if (n < p.n_iter) {
+        // always a load from inside the clip (clamped), never a select on the loaded value: nothing here waits for memory
+        const int k = k_lo + t + n * NT;
+        pre[n] = src[min(max(k, 0), p.L - 1)];
+      }
+  };
+  if ((int)blockIdx.x < total) fetch(blockIdx.x);
+  for (int work = blockIdx.x; work < total; work += gridDim.x) {
+    const int b = work / p.tiles, tile = work - b * p.tiles;
+    const int k_lo = p.q0 + tile * (R * p.qstep) - (TP - 1);
+#pragma unroll
+    for (int n = 0; n < kStageRegs; ++n)
+      if (n < p.n_iter) {
+        const int i = t + n * NT, k = k_lo + i;
+        if (i < p.stage_count) {
+          float v = 0.0f;
+          if (k >= 0 && k < p.L) {
+            if constexpr (std::is_same<T, float>::value) v = pre[n];
+            else v = (float)pre[n] / p.div;
+          }
+          xs[i] = v;
+        }
+      }
     __syncthreads();
+    if (work + (int)gridDim.x < total) fetch(work + gridDim.x);
+    float acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0.0f;
+    int lo_here = lo;
+    asm volatile("" : "+v"(lo_here));  // addresses derived from it are formed per tile, not kept in registers across tiles
+    const float* mine = xs + lo_here;
+    // four taps of all R groups per step; the reads of the next step are issued before the arithmetic of this one
+    // (pinned: left alone, the compiler issues every read of the tile up front and runs out of registers)
+    float xv[2][4][R];
+    auto load = [&](int buf, int i0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int r = 0; r < R; ++r) xv[buf][e][r] = mine[i0 + e + r * p.qstep];
+    };
+    load(0, 0);
+#pragma unroll
+    for (int i0 = 0; i0 < TP; i0 += 4) {  // oldest input first, as scipy accumulates
+      if (i0 + 4 < TP) load(((i0 / 4) + 1) & 1, i0 + 4);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+          acc[r] = __fadd_rn(acc[r], __fmul_rn(xv[(i0 / 4) & 1][e][r], c[TP - 1 - i0 - e]));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) ys[r * NT + o] = acc[r];
+    __syncthreads();
+    float* dst = p.out + (int64_t)b * p.out_stride;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int m = (tile * R + r) * NT + t;
+      if (m < p.n_out) dst[m] = ys[r * NT + t];
+    }
   }
 }
 
@@ -95,6 +150,7 @@ using namespace sed;
 
 struct sed_resampler {
   int32_t up = 1, down = 1, taps = 1, tp = 32, n_pre_remove = 0;
+  int32_t threads = 256, periods = 1, groups = 1, q0 = 0, qstep = 0, stage_count = 0, perm = 1;
   int device = 0, num_cus = 256;
   std::vector<float> table_host;  // [up][taps]
   float* d_table = nullptr;       // [up][tp]
@@ -140,10 +196,64 @@ extern "C" int sed_resampler_create(int32_t orig_sr, int32_t target_sr, sed_resa
       r->table_host[(size_t)(idx % up) * r->taps + idx / up] = hv;
     }
   }
-  r->tp = r->taps <= 32 ? 32 : r->taps <= 64 ? 64 : 128;
-  if (up > 1024 || r->taps > 128) {  // a thread per phase, a register per coefficient
+  static const int kSizes[] = {16, 32, 48, 56, 64, 96, 128};
+  r->tp = 0;
+  for (int sz : kSizes)
+    if (r->tp == 0 && r->taps <= sz) r->tp = sz;
+  const int max_threads = 512;
+  if (r->tp == 0 || up > max_threads) {  // a thread per phase, a register per coefficient
     delete r;
     return SED_ERR_BAD_ARG;
+  }
+  // P periods of `up` outputs per group: about 256 threads; R groups per tile, as many of {4, 2, 1} as the staging
+  // registers and 48 KB of LDS allow
+  r->periods = std::max(1, std::min(max_threads / up, (256 + up - 1) / up));
+  r->threads = up * r->periods;
+  r->q0 = (int32_t)(((int64_t)r->n_pre_remove * down) / up);
+  r->qstep = r->periods * down;
+  const int span1 = (int)((((int64_t)r->threads - 1 + r->n_pre_remove) * down) / up) - r->q0 + r->tp;
+  r->groups = 0;
+  for (int R : {4, 2, 1}) {
+    const int64_t count = (int64_t)(R - 1) * r->qstep + span1;
+    if (r->groups == 0 && count <= (int64_t)kStageRegs * r->threads && (count + (int64_t)R * r->threads) * 4 <= 48 * 1024) {
+      r->groups = R;
+      r->stage_count = (int32_t)count;
+    }
+  }
+  if (r->groups == 0) {
+    delete r;
+    return SED_ERR_BAD_ARG;
+  }
+  {
+    // thread -> output permutation o = t * perm mod threads: the one with the fewest LDS bank conflicts of the 4-byte
+    // reads (counted per 32 lanes over 32 banks and per 64 lanes over 64 banks, over every wavefront of the group)
+    const int NT = r->threads;
+    long best = -1;
+    std::vector<int> pos(NT);
+    for (int perm = 1; perm < std::max(2, NT); ++perm) {
+      if (std::gcd(perm, NT) != 1) continue;
+      for (int t = 0; t < NT; ++t) {
+        const int o = (int)(((int64_t)t * perm) % NT);
+        pos[t] = (int)((((int64_t)o + r->n_pre_remove) * down) / up) - r->q0;
+      }
+      long cost = 0;
+      for (int t0 = 0; t0 < NT; t0 += 32) {
+        int hits[32] = {0};
+        int worst = 0;
+        for (int t = t0; t < std::min(NT, t0 + 32); ++t) worst = std::max(worst, ++hits[pos[t] % 32]);
+        cost += worst;
+      }
+      for (int t0 = 0; t0 < NT; t0 += 64) {
+        int hits[64] = {0};
+        int worst = 0;
+        for (int t = t0; t < std::min(NT, t0 + 64); ++t) worst = std::max(worst, ++hits[pos[t] % 64]);
+        cost += worst;
+      }
+      if (best < 0 || cost < best) {
+        best = cost;
+        r->perm = perm;
+      }
+    }
   }
   int rc = rs_status(hipGetDevice(&r->device));
   hipDeviceProp_t prop;
@@ -185,17 +295,25 @@ extern "C" int sed_resampler_get_filter(const sed_resampler* r, int32_t* up, int
   return SED_OK;
 }
 
-template <int TP>
-static int launch_resample(const sed_resampler* r, ResampleParams p, int32_t pcm_kind, int threads, size_t lds,
-                           int blocks, hipStream_t stream) {
+template <int TP, int R>
+static int launch_resample_r(const ResampleParams& p, int32_t pcm_kind, int threads, size_t lds, int blocks,
+                             hipStream_t stream) {
   if (pcm_kind == SED_PCM_F32) {
-    auto kern = resample_kernel<TP, float>;
+    auto kern = resample_kernel<TP, R, float>;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, stream, p);
   } else {
-    auto kern = resample_kernel<TP, int16_t>;
+    auto kern = resample_kernel<TP, R, int16_t>;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, stream, p);
   }
   return rs_status(hipGetLastError());
+}
+
+template <int TP>
+static int launch_resample(int groups, const ResampleParams& p, int32_t pcm_kind, int threads, size_t lds, int blocks,
+                           hipStream_t stream) {
+  if (groups == 4) return launch_resample_r<TP, 4>(p, pcm_kind, threads, lds, blocks, stream);
+  if (groups == 2) return launch_resample_r<TP, 2>(p, pcm_kind, threads, lds, blocks, stream);
+  return launch_resample_r<TP, 1>(p, pcm_kind, threads, lds, blocks, stream);
 }
 
 extern "C" int sed_resampler_forward(const sed_resampler* r, const void* pcm, int32_t pcm_kind, float pcm_divisor,
@@ -208,40 +326,44 @@ extern "C" int sed_resampler_forward(const sed_resampler* r, const void* pcm, in
   if (out_stride < n_out) return SED_ERR_BAD_ARG;
   if (B == 0 || n_out == 0) return SED_OK;
   if (!pcm || !out) return SED_ERR_BAD_ARG;
+  // the kernel indexes samples within a clip and tiles within the batch with 32-bit integers
+  if (L > INT32_MAX / 2 || n_out > INT32_MAX / 2) return SED_ERR_BAD_ARG;
   int dev = -1;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return rs_status(e);
   if (dev != r->device) return SED_ERR_WRONG_DEVICE;
-  // P periods of `up` outputs per tile: about 256 threads, at most 1024 (512 when a thread holds 128 coefficients)
-  const int max_threads = r->tp > 64 ? 512 : 1024;
-  if (r->up > max_threads) return SED_ERR_BAD_ARG;
-  const int P = std::max(1, std::min(max_threads / r->up, (256 + r->up - 1) / r->up));
-  const int threads = r->up * P;
+  const int threads = r->threads, R = r->groups;
   ResampleParams p;
   p.pcm = pcm;
   p.out = out;
   p.table = r->d_table;
   p.B = B;
-  p.L = L;
+  p.L = (int32_t)L;
   p.pcm_stride = pcm_stride;
   p.out_stride = out_stride;
-  p.n_out = n_out;
-  p.tiles = (n_out + threads - 1) / threads;
+  p.n_out = (int32_t)n_out;
+  p.tiles = (int32_t)((n_out + (int64_t)R * threads - 1) / ((int64_t)R * threads));
+  if (B * p.tiles > INT32_MAX / 2) return SED_ERR_BAD_ARG;
   p.up = r->up;
   p.down = r->down;
   p.n_pre_remove = r->n_pre_remove;
-  p.qstep = P * r->down;
+  p.q0 = r->q0;
+  p.qstep = r->qstep;
+  p.stage_count = r->stage_count;
+  p.perm = r->perm;
+  p.n_iter = (r->stage_count + threads - 1) / threads;
   p.div = pcm_kind == SED_PCM_I16 ? pcm_divisor : 1.0f;
-  // inputs of a tile: from (oldest tap of thread 0) to (newest sample of the last thread)
-  const int64_t q_0 = ((int64_t)r->n_pre_remove * r->down) / r->up;
-  const int64_t q_last = (((int64_t)threads - 1 + r->n_pre_remove) * r->down) / r->up;
-  p.stage_count = (int32_t)(q_last - q_0) + r->tp;
-  const size_t lds = (size_t)p.stage_count * sizeof(float);
-  if (lds > 64 * 1024) return SED_ERR_BAD_ARG;
+  const size_t lds = (size_t)(r->stage_count + R * threads) * sizeof(float);
   const int64_t total = B * p.tiles;
-  const int blocks = (int)std::min<int64_t>(total, (int64_t)r->num_cus * std::max(1, 2048 / threads) * 2);
+  const int blocks = (int)std::min<int64_t>(total, (int64_t)r->num_cus * std::max(1, 2048 / threads));
   hipStream_t s = (hipStream_t)stream;
-  if (r->tp == 32) return launch_resample<32>(r, p, pcm_kind, threads, lds, blocks, s);
-  if (r->tp == 64) return launch_resample<64>(r, p, pcm_kind, threads, lds, blocks, s);
-  return launch_resample<128>(r, p, pcm_kind, threads, lds, blocks, s);
+  switch (r->tp) {
+    case 16: return launch_resample<16>(R, p, pcm_kind, threads, lds, blocks, s);
+    case 32: return launch_resample<32>(R, p, pcm_kind, threads, lds, blocks, s);
+    case 48: return launch_resample<48>(R, p, pcm_kind, threads, lds, blocks, s);
+    case 56: return launch_resample<56>(R, p, pcm_kind, threads, lds, blocks, s);
+    case 64: return launch_resample<64>(R, p, pcm_kind, threads, lds, blocks, s);
+    case 96: return launch_resample<96>(R, p, pcm_kind, threads, lds, blocks, s);
+    default: return launch_resample<128>(R, p, pcm_kind, threads, lds, blocks, s);
+  }
 }
