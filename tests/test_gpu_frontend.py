@@ -427,3 +427,28 @@ def test_all_flavours_against_committed_vectors():
         if not axis_last:                                                # (B, mel, T) -> mel last for the per-frame peak
             got, gold, ref32 = got.swapaxes(-1, -2), gold.swapaxes(-1, -2), ref32.swapaxes(-1, -2)
         _check(got, gold, ref32, span, deep_factor=2.5 if name.startswith("kaldi") else 1.5)
+
+
+def test_random_htsat_style_configurations():
+    """Seeded sweep over sample rate, n_fft, hop (any multiple of 4), mel count and band edges in the torchlibrosa
+    flavour (centred, reflect padding, power, Slaney mel, dB) against the oracle at the usual tolerance."""
+    import sed_amd
+    dev = _dev()
+    rng = np.random.default_rng(2024)
+    for case in range(14):
+        n_fft = int(rng.choice([512, 1024, 2048]))
+        sr = int(rng.choice([8000, 16000, 22050, 32000, 44100, 48000]))
+        hop = 4 * int(rng.integers(8, n_fft // 4 + 1))
+        n_mels = int(rng.integers(1, 129))
+        fmin = float(rng.choice([0.0, 20.0, 50.0, 125.0, 300.0]))
+        fmax = float(rng.uniform(max(fmin + 500.0, 0.2 * sr), 0.5 * sr))
+        n = int(rng.integers(n_fft // 2 + 1, 3 * sr // 4))
+        B = int(rng.integers(1, 4))
+        x = of.synth_batch(B, n, sr, first=300 + case)
+        cfg = sed_amd.FrontendConfig.htsat(sample_rate=sr, window_size=n_fft, hop_size=hop, mel_bins=n_mels, fmin=fmin, fmax=fmax)
+        got = sed_amd.LogMelFrontend(cfg)(torch.from_numpy(x).to(dev))[:, 0].cpu().numpy()
+        gold = of.htsat_logmel(x, sr, n_fft, hop, n_mels, fmin, fmax, mode="gold")[:, 0]
+        ref32 = of.htsat_logmel(x, sr, n_fft, hop, n_mels, fmin, fmax, mode="ref32")[:, 0]
+        assert got.shape == gold.shape == (B, 1 + n // hop, n_mels), (case, sr, n_fft, hop, n_mels)
+        print(case, sr, n_fft, hop, n_mels, fmin, round(fmax, 1), n, end=": ")
+        _check(got, gold, ref32, NEAR_DB)
