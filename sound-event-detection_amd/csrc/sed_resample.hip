@@ -28,15 +28,15 @@ struct ResampleParams {
   float* out;
   const float* table;  // [up][TP]: table[phase][j] = padded filter[phase + up*j], zero beyond the filter
   int64_t B, pcm_stride, out_stride;
-  int32_t L, n_out, tiles, up, down, n_pre_remove, q0, qstep, stage_count, perm, n_iter;
+  const int32_t* assign;  // [blockDim.x] output of a group owned by each thread
+  int32_t L, n_out, tiles, up, down, n_pre_remove, q0, qstep, stage_count, n_iter;
   float div;
 };
 
 constexpr int kStageRegs = 16;
 
-// Tile = R groups of blockDim.x consecutive outputs.  Thread t owns output o = (t * perm) % blockDim.x of every group
-// (perm is coprime with the group length and chosen on the host so that the lanes of a wavefront spread over the LDS
-// banks): the group length is a multiple of `up`, so the thread meets one filter phase only and keeps its TP
+// Tile = R groups of blockDim.x consecutive outputs.  Thread t owns output o = assign[t] of every group (a permutation
+// made on the host so that the lanes of a wavefront read from different LDS banks): the group length is a multiple of `up`, so the thread meets one filter phase only and keeps its TP
 // coefficients in registers.  The input span of a tile is staged in LDS once; the span of the next tile is fetched
 // into registers while the current one is computed.
 template <int TP, int R, typename T>
@@ -45,7 +45,7 @@ __global__ void __launch_bounds__(512) resample_kernel(const ResampleParams p) {
   const int t = threadIdx.x, NT = blockDim.x;
   float* xs = lds;                   // [stage_count] input span of the tile
   float* ys = lds + p.stage_count;   // [R][NT] outputs of the tile in natural order
-  const int o = (int)(((int64_t)t * p.perm) % NT);
+  const int o = p.assign[t];
   const int64_t tt = ((int64_t)o + p.n_pre_remove) * p.down;
   const int phase = (int)(tt % p.up);
   const int lo = (int)(tt / p.up) - p.q0;  // oldest input of output o (group 0) within the span
@@ -150,7 +150,9 @@ using namespace sed;
 
 struct sed_resampler {
   int32_t up = 1, down = 1, taps = 1, tp = 32, n_pre_remove = 0;
-  int32_t threads = 256, periods = 1, groups = 1, q0 = 0, qstep = 0, stage_count = 0, perm = 1;
+  int32_t threads = 256, periods = 1, groups = 1, q0 = 0, qstep = 0, stage_count = 0;
+  std::vector<int32_t> assign;    // [threads] output of a group owned by each thread
+  int32_t* d_assign = nullptr;
   int device = 0, num_cus = 256;
   std::vector<float> table_host;  // [up][taps]
   float* d_table = nullptr;       // [up][tp]
@@ -225,35 +227,31 @@ extern "C" int sed_resampler_create(int32_t orig_sr, int32_t target_sr, sed_resa
     return SED_ERR_BAD_ARG;
   }
   {
-    // thread -> output permutation o = t * perm mod threads: the one with the fewest LDS bank conflicts of the 4-byte
-    // reads (counted per 32 lanes over 32 banks and per 64 lanes over 64 banks, over every wavefront of the group)
+    // thread -> output assignment of a group: every wavefront gets outputs whose first LDS read falls into 64 different
+    // banks (lane = bank; lanes i and i + 32 then also differ modulo 32), as far as the residues allow; later taps and
+    // groups shift every lane by the same amount, so the property holds for all reads.  Leftovers fill the holes.
     const int NT = r->threads;
-    long best = -1;
-    std::vector<int> pos(NT);
-    for (int perm = 1; perm < std::max(2, NT); ++perm) {
-      if (std::gcd(perm, NT) != 1) continue;
-      for (int t = 0; t < NT; ++t) {
-        const int o = (int)(((int64_t)t * perm) % NT);
-        pos[t] = (int)((((int64_t)o + r->n_pre_remove) * down) / up) - r->q0;
-      }
-      long cost = 0;
-      for (int t0 = 0; t0 < NT; t0 += 32) {
-        int hits[32] = {0};
-        int worst = 0;
-        for (int t = t0; t < std::min(NT, t0 + 32); ++t) worst = std::max(worst, ++hits[pos[t] % 32]);
-        cost += worst;
-      }
-      for (int t0 = 0; t0 < NT; t0 += 64) {
-        int hits[64] = {0};
-        int worst = 0;
-        for (int t = t0; t < std::min(NT, t0 + 64); ++t) worst = std::max(worst, ++hits[pos[t] % 64]);
-        cost += worst;
-      }
-      if (best < 0 || cost < best) {
-        best = cost;
-        r->perm = perm;
+    std::vector<std::vector<int>> bucket(64);
+    for (int o = NT - 1; o >= 0; --o) {
+      const int pos = (int)((((int64_t)o + r->n_pre_remove) * down) / up) - r->q0;
+      bucket[pos % 64].push_back(o);
+    }
+    r->assign.assign(NT, -1);
+    for (int t = 0; t < NT; ++t) {
+      auto& bk = bucket[t % 64];
+      if (!bk.empty()) {
+        r->assign[t] = bk.back();
+        bk.pop_back();
       }
     }
+    std::vector<int> rest;
+    for (auto& bk : bucket)
+      for (int o : bk) rest.push_back(o);
+    for (int t = 0; t < NT; ++t)
+      if (r->assign[t] < 0) {
+        r->assign[t] = rest.back();
+        rest.pop_back();
+      }
   }
   int rc = rs_status(hipGetDevice(&r->device));
   hipDeviceProp_t prop;
@@ -264,8 +262,11 @@ extern "C" int sed_resampler_create(int32_t orig_sr, int32_t target_sr, sed_resa
     for (int j = 0; j < r->taps; ++j) padded[(size_t)ph * r->tp + j] = r->table_host[(size_t)ph * r->taps + j];
   if (!rc) rc = rs_status(hipMalloc((void**)&r->d_table, padded.size() * sizeof(float)));
   if (!rc) rc = rs_status(hipMemcpy(r->d_table, padded.data(), padded.size() * sizeof(float), hipMemcpyHostToDevice));
+  if (!rc) rc = rs_status(hipMalloc((void**)&r->d_assign, r->assign.size() * sizeof(int32_t)));
+  if (!rc) rc = rs_status(hipMemcpy(r->d_assign, r->assign.data(), r->assign.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   if (rc) {
     if (r->d_table) (void)hipFree(r->d_table);
+    if (r->d_assign) (void)hipFree(r->d_assign);
     delete r;
     return rc;
   }
@@ -276,6 +277,7 @@ extern "C" int sed_resampler_create(int32_t orig_sr, int32_t target_sr, sed_resa
 extern "C" void sed_resampler_destroy(sed_resampler* r) {
   if (!r) return;
   if (r->d_table) (void)hipFree(r->d_table);
+  if (r->d_assign) (void)hipFree(r->d_assign);
   delete r;
 }
 
@@ -350,7 +352,7 @@ extern "C" int sed_resampler_forward(const sed_resampler* r, const void* pcm, in
   p.q0 = r->q0;
   p.qstep = r->qstep;
   p.stage_count = r->stage_count;
-  p.perm = r->perm;
+  p.assign = r->d_assign;
   p.n_iter = (r->stage_count + threads - 1) / threads;
   p.div = pcm_kind == SED_PCM_I16 ? pcm_divisor : 1.0f;
   const size_t lds = (size_t)(r->stage_count + R * threads) * sizeof(float);
