@@ -33,7 +33,7 @@ struct ResampleParams {
   float div;
 };
 
-constexpr int kStageRegs = 16;
+constexpr int stage_regs(int groups) { return groups >= 8 ? 24 : 16; }  // staging registers per thread
 
 // Tile = R groups of blockDim.x consecutive outputs.  Thread t owns output o = assign[t] of every group (a permutation
 // made on the host so that the lanes of a wavefront read from different LDS banks): the group length is a multiple of `up`, so the thread meets one filter phase only and keeps its TP
@@ -52,6 +52,7 @@ __global__ void __launch_bounds__(512) resample_kernel(const ResampleParams p) {
   float c[TP];
 #pragma unroll
   for (int j = 0; j < TP; ++j) c[j] = p.table[phase * TP + j];
+  constexpr int kStageRegs = stage_regs(R);
   T pre[kStageRegs];
   const int total = (int)p.B * p.tiles;
   auto fetch = [&](int work) {
@@ -93,23 +94,24 @@ __global__ void __launch_bounds__(512) resample_kernel(const ResampleParams p) {
     const float* mine = xs + lo_here;
     // four taps of all R groups per step; the reads of the next step are issued before the arithmetic of this one
     // (pinned: left alone, the compiler issues every read of the tile up front and runs out of registers)
-    float xv[2][4][R];
+    constexpr int S = R >= 8 ? 2 : 4;  // taps per step: 16 reads in flight per step whatever R is
+    float xv[2][S][R];
     auto load = [&](int buf, int i0) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
+      for (int e = 0; e < S; ++e)
 #pragma unroll
         for (int r = 0; r < R; ++r) xv[buf][e][r] = mine[i0 + e + r * p.qstep];
     };
     load(0, 0);
 #pragma unroll
-    for (int i0 = 0; i0 < TP; i0 += 4) {  // oldest input first, as scipy accumulates
-      if (i0 + 4 < TP) load(((i0 / 4) + 1) & 1, i0 + 4);
+    for (int i0 = 0; i0 < TP; i0 += S) {  // oldest input first, as scipy accumulates
+      if (i0 + S < TP) load(((i0 / S) + 1) & 1, i0 + S);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
+      for (int e = 0; e < S; ++e)
 #pragma unroll
         for (int r = 0; r < R; ++r)
-          acc[r] = __fadd_rn(acc[r], __fmul_rn(xv[(i0 / 4) & 1][e][r], c[TP - 1 - i0 - e]));
+          acc[r] = __fadd_rn(acc[r], __fmul_rn(xv[(i0 / S) & 1][e][r], c[TP - 1 - i0 - e]));
       __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
@@ -215,9 +217,9 @@ extern "C" int sed_resampler_create(int32_t orig_sr, int32_t target_sr, sed_resa
   r->qstep = r->periods * down;
   const int span1 = (int)((((int64_t)r->threads - 1 + r->n_pre_remove) * down) / up) - r->q0 + r->tp;
   r->groups = 0;
-  for (int R : {4, 2, 1}) {
+  for (int R : {8, 4, 2, 1}) {
     const int64_t count = (int64_t)(R - 1) * r->qstep + span1;
-    if (r->groups == 0 && count <= (int64_t)kStageRegs * r->threads && (count + (int64_t)R * r->threads) * 4 <= 48 * 1024) {
+    if (r->groups == 0 && count <= (int64_t)stage_regs(R) * r->threads && (count + (int64_t)R * r->threads) * 4 <= 48 * 1024) {
       r->groups = R;
       r->stage_count = (int32_t)count;
     }
@@ -313,6 +315,7 @@ static int launch_resample_r(const ResampleParams& p, int32_t pcm_kind, int thre
 template <int TP>
 static int launch_resample(int groups, const ResampleParams& p, int32_t pcm_kind, int threads, size_t lds, int blocks,
                            hipStream_t stream) {
+  if (groups == 8) return launch_resample_r<TP, 8>(p, pcm_kind, threads, lds, blocks, stream);
   if (groups == 4) return launch_resample_r<TP, 4>(p, pcm_kind, threads, lds, blocks, stream);
   if (groups == 2) return launch_resample_r<TP, 2>(p, pcm_kind, threads, lds, blocks, stream);
   return launch_resample_r<TP, 1>(p, pcm_kind, threads, lds, blocks, stream);
