@@ -29,7 +29,7 @@ struct ResampleParams {
   const float* table;  // [up][TP]: table[phase][j] = padded filter[phase + up*j], zero beyond the filter
   int64_t B, pcm_stride, out_stride;
   const int32_t* assign;  // [blockDim.x] output of a group owned by each thread
-  int32_t L, n_out, tiles, up, down, n_pre_remove, q0, qstep, stage_count, n_iter;
+  int32_t L, n_out, tiles, up, down, n_pre_remove, q0, qstep, stage_count, n_iter, span_stride;
   float div;
 };
 
@@ -126,6 +126,102 @@ __global__ void __launch_bounds__(512) resample_kernel(const ResampleParams p) {
   }
 }
 
+// The same computation for fp32 input with the span moved from global memory straight into LDS (LDS-DMA, 4 bytes per
+// lane so that any sample alignment works), double buffered: the span of tile i+1 is in flight while tile i is computed,
+// no staging registers, one workgroup barrier per tile.  blockDim.x is a multiple of 64.
+//   buffers: xs[2][span_stride] (span_stride = DMA rounds x blockDim.x >= stage_count), ys[2][R][blockDim.x]
+template <int TP, int R>
+__global__ void __launch_bounds__(512) resample_dma_kernel(const ResampleParams p) {
+  extern __shared__ __align__(16) float lds[];
+  const int t = threadIdx.x, NT = blockDim.x;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+  float* xs = lds;
+  float* ys = lds + 2 * p.span_stride;
+  const int o = p.assign[t];
+  const int64_t tt = ((int64_t)o + p.n_pre_remove) * p.down;
+  const int phase = (int)(tt % p.up);
+  const int lo = (int)(tt / p.up) - p.q0;
+  float c[TP];
+#pragma unroll
+  for (int j = 0; j < TP; ++j) c[j] = p.table[phase * TP + j];
+  const int total = (int)p.B * p.tiles;
+  // issue: wave w moves samples [64 (w + n NT/64), +64) of the span in round n; addresses are clamped into the clip
+  auto issue = [&](int work, float* dstbuf) {
+    const int b = work / p.tiles, tile = work - b * p.tiles;
+    const int k_lo = p.q0 + tile * (R * p.qstep) - (TP - 1);
+    const float* src = (const float*)p.pcm + (int64_t)b * p.pcm_stride;
+    for (int n = 0; n < p.n_iter; ++n) {
+      const int i0 = n * NT + 64 * wave;
+      const int k = min(max(k_lo + i0 + lane, 0), p.L - 1);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + k),
+                                       (__attribute__((address_space(3))) void*)(dstbuf + i0), 4, 0, 0);
+    }
+  };
+  // after the wave's own transfers have landed: zeros where the span reaches outside the clip (first / last tiles)
+  auto fix_edges = [&](int work, float* dstbuf) {
+    const int b = work / p.tiles, tile = work - b * p.tiles;
+    const int k_lo = p.q0 + tile * (R * p.qstep) - (TP - 1);
+    if (k_lo >= 0 && k_lo + p.n_iter * NT <= p.L) return;  // wave-uniform
+    for (int n = 0; n < p.n_iter; ++n) {
+      const int i = n * NT + 64 * wave + lane, k = k_lo + i;
+      if (k < 0 || k >= p.L) dstbuf[i] = 0.0f;
+    }
+  };
+  if ((int)blockIdx.x < total) {
+    issue(blockIdx.x, xs);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    fix_edges(blockIdx.x, xs);
+  }
+  __syncthreads();
+  int parity = 0;
+  for (int work = blockIdx.x; work < total; work += gridDim.x, parity ^= 1) {
+    const int b = work / p.tiles, tile = work - b * p.tiles;
+    const float* cur = xs + parity * p.span_stride;
+    float* nxt = xs + (parity ^ 1) * p.span_stride;
+    float* yb = ys + parity * (R * NT);
+    const bool more = work + (int)gridDim.x < total;
+    if (more) issue(work + gridDim.x, nxt);
+    float acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0.0f;
+    int lo_here = lo;
+    asm volatile("" : "+v"(lo_here));  // addresses derived from it are formed per tile, not kept in registers across tiles
+    const float* mine = cur + lo_here;
+    constexpr int S = R >= 8 ? 2 : 4;
+    float xv[2][S][R];
+    auto load = [&](int buf, int i0) {
+#pragma unroll
+      for (int e = 0; e < S; ++e)
+#pragma unroll
+        for (int r = 0; r < R; ++r) xv[buf][e][r] = mine[i0 + e + r * p.qstep];
+    };
+    load(0, 0);
+#pragma unroll
+    for (int i0 = 0; i0 < TP; i0 += S) {  // oldest input first, as scipy accumulates
+      if (i0 + S < TP) load(((i0 / S) + 1) & 1, i0 + S);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int e = 0; e < S; ++e)
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+          acc[r] = __fadd_rn(acc[r], __fmul_rn(xv[(i0 / S) & 1][e][r], c[TP - 1 - i0 - e]));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) yb[r * NT + o] = acc[r];
+    // the next span has had the whole tile to land; the stores below are issued after this wait, so it never waits for them
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (more) fix_edges(work + gridDim.x, nxt);
+    __syncthreads();
+    float* dst = p.out + (int64_t)b * p.out_stride;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int m = (tile * R + r) * NT + t;
+      if (m < p.n_out) dst[m] = yb[r * NT + t];
+    }
+  }
+}
+
 static double bessel_i0(double x) {
   const double q = 0.25 * x * x;
   double term = 1.0, total = 1.0;
@@ -153,6 +249,7 @@ using namespace sed;
 struct sed_resampler {
   int32_t up = 1, down = 1, taps = 1, tp = 32, n_pre_remove = 0;
   int32_t threads = 256, periods = 1, groups = 1, q0 = 0, qstep = 0, stage_count = 0;
+  int32_t dma_groups = 0, dma_stage_count = 0, dma_rounds = 0;  // LDS-DMA variant (fp32 input), 0 groups: not available
   std::vector<int32_t> assign;    // [threads] output of a group owned by each thread
   int32_t* d_assign = nullptr;
   int device = 0, num_cus = 256;
@@ -228,6 +325,16 @@ extern "C" int sed_resampler_create(int32_t orig_sr, int32_t target_sr, sed_resa
     delete r;
     return SED_ERR_BAD_ARG;
   }
+  if (r->threads % 64 == 0)
+    for (int R : {4, 2, 1}) {  // two span buffers and two output buffers in at most 48 KB
+      const int64_t count = (int64_t)(R - 1) * r->qstep + span1;
+      const int64_t rounds = (count + r->threads - 1) / r->threads;
+      if (r->dma_groups == 0 && (2 * rounds * r->threads + 2 * (int64_t)R * r->threads) * 4 <= 48 * 1024) {
+        r->dma_groups = R;
+        r->dma_stage_count = (int32_t)count;
+        r->dma_rounds = (int32_t)rounds;
+      }
+    }
   {
     // thread -> output assignment of a group: every wavefront gets outputs whose first LDS read falls into 64 different
     // banks (lane = bank; lanes i and i + 32 then also differ modulo 32), as far as the residues allow; later taps and
@@ -313,6 +420,14 @@ static int launch_resample_r(const ResampleParams& p, int32_t pcm_kind, int thre
 }
 
 template <int TP>
+static int launch_resample_dma(int groups, const ResampleParams& p, int threads, size_t lds, int blocks, hipStream_t stream) {
+  if (groups == 4) hipLaunchKernelGGL((resample_dma_kernel<TP, 4>), dim3(blocks), dim3(threads), lds, stream, p);
+  else if (groups == 2) hipLaunchKernelGGL((resample_dma_kernel<TP, 2>), dim3(blocks), dim3(threads), lds, stream, p);
+  else hipLaunchKernelGGL((resample_dma_kernel<TP, 1>), dim3(blocks), dim3(threads), lds, stream, p);
+  return rs_status(hipGetLastError());
+}
+
+template <int TP>
 static int launch_resample(int groups, const ResampleParams& p, int32_t pcm_kind, int threads, size_t lds, int blocks,
                            hipStream_t stream) {
   if (groups == 8) return launch_resample_r<TP, 8>(p, pcm_kind, threads, lds, blocks, stream);
@@ -337,7 +452,8 @@ extern "C" int sed_resampler_forward(const sed_resampler* r, const void* pcm, in
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return rs_status(e);
   if (dev != r->device) return SED_ERR_WRONG_DEVICE;
-  const int threads = r->threads, R = r->groups;
+  const bool dma = pcm_kind == SED_PCM_F32 && r->dma_groups > 0 && (uintptr_t)pcm % 4 == 0 && getenv("SED_RS_NO_DMA") == nullptr;
+  const int threads = r->threads, R = dma ? r->dma_groups : r->groups;
   ResampleParams p;
   p.pcm = pcm;
   p.out = out;
@@ -354,14 +470,25 @@ extern "C" int sed_resampler_forward(const sed_resampler* r, const void* pcm, in
   p.n_pre_remove = r->n_pre_remove;
   p.q0 = r->q0;
   p.qstep = r->qstep;
-  p.stage_count = r->stage_count;
+  p.stage_count = dma ? r->dma_stage_count : r->stage_count;
   p.assign = r->d_assign;
-  p.n_iter = (r->stage_count + threads - 1) / threads;
+  p.n_iter = dma ? r->dma_rounds : (r->stage_count + threads - 1) / threads;
+  p.span_stride = r->dma_rounds * threads;
   p.div = pcm_kind == SED_PCM_I16 ? pcm_divisor : 1.0f;
-  const size_t lds = (size_t)(r->stage_count + R * threads) * sizeof(float);
+  const size_t lds = dma ? (size_t)(2 * p.span_stride + 2 * R * threads) * sizeof(float)
+                         : (size_t)(r->stage_count + R * threads) * sizeof(float);
   const int64_t total = B * p.tiles;
   const int blocks = (int)std::min<int64_t>(total, (int64_t)r->num_cus * std::max(1, 2048 / threads));
   hipStream_t s = (hipStream_t)stream;
+  if (dma) switch (r->tp) {
+      case 16: return launch_resample_dma<16>(R, p, threads, lds, blocks, s);
+      case 32: return launch_resample_dma<32>(R, p, threads, lds, blocks, s);
+      case 48: return launch_resample_dma<48>(R, p, threads, lds, blocks, s);
+      case 56: return launch_resample_dma<56>(R, p, threads, lds, blocks, s);
+      case 64: return launch_resample_dma<64>(R, p, threads, lds, blocks, s);
+      case 96: return launch_resample_dma<96>(R, p, threads, lds, blocks, s);
+      default: return launch_resample_dma<128>(R, p, threads, lds, blocks, s);
+    }
   switch (r->tp) {
     case 16: return launch_resample<16>(R, p, pcm_kind, threads, lds, blocks, s);
     case 32: return launch_resample<32>(R, p, pcm_kind, threads, lds, blocks, s);
