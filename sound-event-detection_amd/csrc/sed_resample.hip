@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <numeric>
 #include <vector>
@@ -31,6 +32,7 @@ struct ResampleParams {
   const int32_t* assign;  // [blockDim.x] output of a group owned by each thread
   int32_t L, n_out, tiles, up, down, n_pre_remove, q0, qstep, stage_count, n_iter, span_stride;
   float div;
+  int32_t div3;  // 1: x * (1/div) corrected by two fused steps equals x / div for every int16 x (checked on the host)
 };
 
 constexpr int stage_regs(int groups) { return groups >= 8 ? 24 : 16; }  // staging registers per thread
@@ -130,7 +132,7 @@ __global__ void __launch_bounds__(512) resample_kernel(const ResampleParams p) {
 // lane so that any sample alignment works), double buffered: the span of tile i+1 is in flight while tile i is computed,
 // no staging registers, one workgroup barrier per tile.  blockDim.x is a multiple of 64.
 //   buffers: xs[2][span_stride] (span_stride = DMA rounds x blockDim.x >= stage_count), ys[2][R][blockDim.x]
-template <int TP, int R>
+template <int TP, int R, typename T>
 __global__ void __launch_bounds__(512) resample_dma_kernel(const ResampleParams p) {
   extern __shared__ __align__(16) float lds[];
   const int t = threadIdx.x, NT = blockDim.x;
@@ -149,22 +151,42 @@ __global__ void __launch_bounds__(512) resample_dma_kernel(const ResampleParams 
   auto issue = [&](int work, float* dstbuf) {
     const int b = work / p.tiles, tile = work - b * p.tiles;
     const int k_lo = p.q0 + tile * (R * p.qstep) - (TP - 1);
-    const float* src = (const float*)p.pcm + (int64_t)b * p.pcm_stride;
+    const T* src = (const T*)p.pcm + (int64_t)b * p.pcm_stride;
     for (int n = 0; n < p.n_iter; ++n) {
       const int i0 = n * NT + 64 * wave;
       const int k = min(max(k_lo + i0 + lane, 0), p.L - 1);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + k),
-                                       (__attribute__((address_space(3))) void*)(dstbuf + i0), 4, 0, 0);
+      // (an int16 sample lands zero-extended in the 4-byte LDS slot of its lane)
+      if constexpr (std::is_same<T, float>::value)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + k),
+                                         (__attribute__((address_space(3))) void*)(dstbuf + i0), 4, 0, 0);
+      else
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + k),
+                                         (__attribute__((address_space(3))) void*)(dstbuf + i0), 2, 0, 0);
     }
   };
   // after the wave's own transfers have landed: zeros where the span reaches outside the clip (first / last tiles)
   auto fix_edges = [&](int work, float* dstbuf) {
     const int b = work / p.tiles, tile = work - b * p.tiles;
     const int k_lo = p.q0 + tile * (R * p.qstep) - (TP - 1);
-    if (k_lo >= 0 && k_lo + p.n_iter * NT <= p.L) return;  // wave-uniform
-    for (int n = 0; n < p.n_iter; ++n) {
-      const int i = n * NT + 64 * wave + lane, k = k_lo + i;
-      if (k < 0 || k >= p.L) dstbuf[i] = 0.0f;
+    if constexpr (std::is_same<T, float>::value) {
+      if (k_lo >= 0 && k_lo + p.n_iter * NT <= p.L) return;  // wave-uniform
+      for (int n = 0; n < p.n_iter; ++n) {
+        const int i = n * NT + 64 * wave + lane, k = k_lo + i;
+        if (k < 0 || k >= p.L) dstbuf[i] = 0.0f;
+      }
+    } else {  // int16: every landed sample is converted in place by the lane that fetched it
+      for (int n = 0; n < p.n_iter; ++n) {
+        const int i = n * NT + 64 * wave + lane, k = k_lo + i;
+        const int raw = (int)(short)(reinterpret_cast<const unsigned int*>(dstbuf)[i] & 0xffffu);
+        float v;
+        if (p.div3) {  // wave-uniform
+          const float rcp = 1.0f / p.div, xf = (float)raw, q = xf * rcp;
+          v = __builtin_fmaf(__builtin_fmaf(-q, p.div, xf), rcp, q);
+        } else {
+          v = (float)raw / p.div;
+        }
+        dstbuf[i] = (k < 0 || k >= p.L) ? 0.0f : v;
+      }
     }
   };
   if ((int)blockIdx.x < total) {
@@ -419,12 +441,18 @@ static int launch_resample_r(const ResampleParams& p, int32_t pcm_kind, int thre
   return rs_status(hipGetLastError());
 }
 
+template <int TP, typename T>
+static int launch_resample_dma_t(int groups, const ResampleParams& p, int threads, size_t lds, int blocks, hipStream_t stream) {
+  if (groups == 4) hipLaunchKernelGGL((resample_dma_kernel<TP, 4, T>), dim3(blocks), dim3(threads), lds, stream, p);
+  else if (groups == 2) hipLaunchKernelGGL((resample_dma_kernel<TP, 2, T>), dim3(blocks), dim3(threads), lds, stream, p);
+  else hipLaunchKernelGGL((resample_dma_kernel<TP, 1, T>), dim3(blocks), dim3(threads), lds, stream, p);
+  return rs_status(hipGetLastError());
+}
+
 template <int TP>
 static int launch_resample_dma(int groups, const ResampleParams& p, int threads, size_t lds, int blocks, hipStream_t stream) {
-  if (groups == 4) hipLaunchKernelGGL((resample_dma_kernel<TP, 4>), dim3(blocks), dim3(threads), lds, stream, p);
-  else if (groups == 2) hipLaunchKernelGGL((resample_dma_kernel<TP, 2>), dim3(blocks), dim3(threads), lds, stream, p);
-  else hipLaunchKernelGGL((resample_dma_kernel<TP, 1>), dim3(blocks), dim3(threads), lds, stream, p);
-  return rs_status(hipGetLastError());
+  if (p.div == 0.0f) return launch_resample_dma_t<TP, float>(groups, p, threads, lds, blocks, stream);
+  return launch_resample_dma_t<TP, int16_t>(groups, p, threads, lds, blocks, stream);
 }
 
 template <int TP>
@@ -434,6 +462,26 @@ static int launch_resample(int groups, const ResampleParams& p, int32_t pcm_kind
   if (groups == 4) return launch_resample_r<TP, 4>(p, pcm_kind, threads, lds, blocks, stream);
   if (groups == 2) return launch_resample_r<TP, 2>(p, pcm_kind, threads, lds, blocks, stream);
   return launch_resample_r<TP, 1>(p, pcm_kind, threads, lds, blocks, stream);
+}
+
+// Whether q = x * rcp, q + fma(-q, d, x) * rcp reproduces the IEEE quotient x / d for all 65536 int16 values; remembered
+// for the few divisors a process ever uses.
+static bool three_step_division_is_exact(float d) {
+  static std::mutex mu;
+  static std::vector<std::pair<float, bool>> seen;
+  std::lock_guard<std::mutex> lock(mu);
+  for (const auto& e : seen)
+    if (std::memcmp(&e.first, &d, sizeof(float)) == 0) return e.second;
+  const float r = 1.0f / d;
+  bool same = std::isfinite(r) && r > 0.0f;
+  for (int x = -32768; same && x <= 32767; ++x) {
+    const float xf = (float)x, q = xf * r;
+    const float q1 = std::fmaf(std::fmaf(-q, d, xf), r, q);
+    const float want = xf / d;
+    same = std::memcmp(&q1, &want, sizeof(float)) == 0 || (q1 == 0.0f && want == 0.0f);
+  }
+  if (seen.size() < 64) seen.emplace_back(d, same);
+  return same;
 }
 
 extern "C" int sed_resampler_forward(const sed_resampler* r, const void* pcm, int32_t pcm_kind, float pcm_divisor,
@@ -452,7 +500,8 @@ extern "C" int sed_resampler_forward(const sed_resampler* r, const void* pcm, in
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return rs_status(e);
   if (dev != r->device) return SED_ERR_WRONG_DEVICE;
-  const bool dma = pcm_kind == SED_PCM_F32 && r->dma_groups > 0 && (uintptr_t)pcm % 4 == 0 && getenv("SED_RS_NO_DMA") == nullptr;
+  const bool dma = r->dma_groups > 0 && (uintptr_t)pcm % (pcm_kind == SED_PCM_F32 ? 4 : 2) == 0 &&
+                   getenv("SED_RS_NO_DMA") == nullptr && (pcm_kind == SED_PCM_F32 || getenv("SED_RS_NO_DMA16") == nullptr);
   const int threads = r->threads, R = dma ? r->dma_groups : r->groups;
   ResampleParams p;
   p.pcm = pcm;
@@ -474,7 +523,8 @@ extern "C" int sed_resampler_forward(const sed_resampler* r, const void* pcm, in
   p.assign = r->d_assign;
   p.n_iter = dma ? r->dma_rounds : (r->stage_count + threads - 1) / threads;
   p.span_stride = r->dma_rounds * threads;
-  p.div = pcm_kind == SED_PCM_I16 ? pcm_divisor : 1.0f;
+  p.div3 = (pcm_kind == SED_PCM_I16 && dma && three_step_division_is_exact(pcm_divisor)) ? 1 : 0;
+  p.div = pcm_kind == SED_PCM_I16 ? pcm_divisor : (dma ? 0.0f : 1.0f);  // (0: fp32 input, for the DMA launcher)
   const size_t lds = dma ? (size_t)(2 * p.span_stride + 2 * R * threads) * sizeof(float)
                          : (size_t)(r->stage_count + R * threads) * sizeof(float);
   const int64_t total = B * p.tiles;

@@ -46,6 +46,13 @@ def test_librosa_signature_int16_and_errors():
     got = sed_amd.resample(torch.from_numpy(s).to(dev), orig_sr=44100, target_sr=16000, pcm_divisor=32768.0)
     want = R.resample_poly_f32(s.astype(np.float32) / np.float32(32768.0), 44100, 16000)
     assert np.array_equal(got.cpu().numpy(), want)
+    s[0, :65536] = np.arange(-32768, 32768, dtype=np.int16)                  # every int16 value once
+    for div in (32767.0, 32768.0, 1234.5, 3.0):                              # exact whatever the divisor
+        got = sed_amd.resample(torch.from_numpy(s).to(dev), orig_sr=44100, target_sr=16000, pcm_divisor=div)
+        want = R.resample_poly_f32(s.astype(np.float32) / np.float32(div), 44100, 16000)
+        assert np.array_equal(got.cpu().numpy(), want), div
+        odd = sed_amd.resample(torch.from_numpy(s).to(dev), orig_sr=44100, target_sr=48000, pcm_divisor=div)  # register path
+        assert np.array_equal(odd.cpu().numpy(), R.librosa_resample_polyphase(s.astype(np.float32) / np.float32(div), 44100, 48000)), div
     stereo = torch.from_numpy(np.stack([x, -x], axis=1)).to(dev)             # (B, channels, L): last axis is resampled
     z = sed_amd.resample(stereo, orig_sr=44100, target_sr=16000)
     assert z.shape == (2, 2, 32000) and torch.equal(z[:, 1], -z[:, 0])
