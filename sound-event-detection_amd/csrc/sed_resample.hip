@@ -3,10 +3,11 @@
 // cast to fp32 and scaled by `up` in fp32; every output sample accumulated in fp32 from the oldest contributing input
 // sample to the newest with separately rounded multiplies and adds.  The results equal scipy's bit for bit.
 //
-// Work decomposition: a workgroup of up*P threads produces up*P consecutive output samples per tile; since the tile
-// length is a multiple of `up`, a thread meets the same filter phase in every tile and keeps that phase's
-// coefficients in registers for the whole launch.  The input samples a tile needs (P*down + taps, contiguous) are
-// staged once in LDS.  Bound: HBM (read L, write L*up/down samples per clip) once the LDS reads are hidden.
+// Work decomposition: a workgroup of up*P threads (about 256) produces R groups of up*P consecutive output samples per
+// tile; a group is a multiple of `up` long, so a thread meets the same filter phase in every group and keeps that
+// phase's coefficients in registers for the whole launch.  The input samples a tile needs (R*P*down + taps, contiguous)
+// are staged once in LDS, either straight from global memory by LDS-DMA (resample_dma_kernel, double buffered) or
+// through registers (resample_kernel).  Bound: HBM (read L, write L*up/down samples per clip).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -38,9 +39,9 @@ struct ResampleParams {
 constexpr int stage_regs(int groups) { return groups >= 8 ? 24 : 16; }  // staging registers per thread
 
 // Tile = R groups of blockDim.x consecutive outputs.  Thread t owns output o = assign[t] of every group (a permutation
-// made on the host so that the lanes of a wavefront read from different LDS banks): the group length is a multiple of `up`, so the thread meets one filter phase only and keeps its TP
-// coefficients in registers.  The input span of a tile is staged in LDS once; the span of the next tile is fetched
-// into registers while the current one is computed.
+// made on the host so that the lanes of a wavefront read from different LDS banks): the group length is a multiple of
+// `up`, so the thread meets one filter phase only and keeps its TP coefficients in registers.  The input span of a
+// tile is staged in LDS once; the span of the next tile is fetched into registers while the current one is computed.
 template <int TP, int R, typename T>
 __global__ void __launch_bounds__(512) resample_kernel(const ResampleParams p) {
   extern __shared__ __align__(16) float lds[];
