@@ -221,7 +221,7 @@ def _run_front(plan: _Plan, x: torch.Tensor, spectrogram: bool) -> torch.Tensor:
         return out
     fn = L.lib.sed_spectrogram_forward if spectrogram else L.lib.sed_logmel_forward
     with torch.cuda.device(x.device):
-        L.check(fn(plan.ptr, x.data_ptr(), B, n, x.stride(0), out.data_ptr(), T * row, L.stream_ptr(x.device)),
+        L.check(fn(plan.ptr, x.data_ptr(), B, n, max(x.stride(0), n), out.data_ptr(), T * row, L.stream_ptr(x.device)),
                 "sed_spectrogram_forward" if spectrogram else "sed_logmel_forward")
     return out
 

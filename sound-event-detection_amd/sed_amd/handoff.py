@@ -46,7 +46,7 @@ def cut_events(pcm: torch.Tensor, sr, events: Sequence[Tuple[int, float, float]]
     d_idx, d_start, d_end = (torch.from_numpy(a).to(dev) for a in (idx, start, end))
     with torch.cuda.device(dev):
         L.check(L.lib.sed_cut_events(pcm.data_ptr(), L.PCM_I16 if pcm.dtype == torch.int16 else L.PCM_F32,
-                                     float(pcm_divisor), S, n, pcm.stride(0), d_idx.data_ptr(), d_start.data_ptr(),
+                                     float(pcm_divisor), S, n, max(pcm.stride(0), n), d_idx.data_ptr(), d_start.data_ptr(),
                                      d_end.data_ptr(), E, clips.data_ptr(), cap, lengths.data_ptr(),
                                      L.stream_ptr(dev)), "sed_cut_events")
     return clips, lengths

@@ -73,7 +73,7 @@ class Resampler:
         n_out = self.out_len(n)
         out = torch.empty((B, n_out), dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
-            L.check(L.lib.sed_resampler_forward(self._h, x.data_ptr(), kind, float(pcm_divisor), B, n, x.stride(0),
+            L.check(L.lib.sed_resampler_forward(self._h, x.data_ptr(), kind, float(pcm_divisor), B, n, max(x.stride(0), n),
                                                 out.data_ptr(), n_out, L.stream_ptr(x.device)), "sed_resampler_forward")
         return out[0] if squeeze else out
 

@@ -174,6 +174,8 @@ def test_edges_ragged_short_empty_strided():
     with pytest.raises(ValueError, match="too short"):
         fe(torch.zeros(1, 512, device=dev))
     assert fe(torch.zeros(0, 4096, device=dev)).shape == (0, 13, 64)
+    one = of.synth_clip(7, 5000, 32000)[None]                             # a (1, n) view whose batch stride numpy leaves at 0
+    assert torch.equal(fe(torch.from_numpy(one).to(dev)), fe(torch.from_numpy(one.copy()).to(dev)))
     big = torch.from_numpy(of.synth_batch(3, 20001, 32000, first=9)).to(dev)
     a = fe(big[:, 1:])                                                    # misaligned rows, row stride != length
     b = fe(big[:, 1:].contiguous())
