@@ -320,7 +320,7 @@ extern "C" int sed_resampler_create(int32_t orig_sr, int32_t target_sr, sed_resa
       r->table_host[(size_t)(idx % up) * r->taps + idx / up] = hv;
     }
   }
-  static const int kSizes[] = {16, 32, 48, 56, 64, 96, 128};
+  static const int kSizes[] = {16, 32, 48, 56, 60, 64, 96, 128};
   r->tp = 0;
   for (int sz : kSizes)
     if (r->tp == 0 && r->taps <= sz) r->tp = sz;
@@ -536,6 +536,7 @@ extern "C" int sed_resampler_forward(const sed_resampler* r, const void* pcm, in
       case 32: return launch_resample_dma<32>(R, p, threads, lds, blocks, s);
       case 48: return launch_resample_dma<48>(R, p, threads, lds, blocks, s);
       case 56: return launch_resample_dma<56>(R, p, threads, lds, blocks, s);
+      case 60: return launch_resample_dma<60>(R, p, threads, lds, blocks, s);
       case 64: return launch_resample_dma<64>(R, p, threads, lds, blocks, s);
       case 96: return launch_resample_dma<96>(R, p, threads, lds, blocks, s);
       default: return launch_resample_dma<128>(R, p, threads, lds, blocks, s);
@@ -545,6 +546,7 @@ extern "C" int sed_resampler_forward(const sed_resampler* r, const void* pcm, in
     case 32: return launch_resample<32>(R, p, pcm_kind, threads, lds, blocks, s);
     case 48: return launch_resample<48>(R, p, pcm_kind, threads, lds, blocks, s);
     case 56: return launch_resample<56>(R, p, pcm_kind, threads, lds, blocks, s);
+    case 60: return launch_resample<60>(R, p, pcm_kind, threads, lds, blocks, s);
     case 64: return launch_resample<64>(R, p, pcm_kind, threads, lds, blocks, s);
     case 96: return launch_resample<96>(R, p, pcm_kind, threads, lds, blocks, s);
     default: return launch_resample<128>(R, p, pcm_kind, threads, lds, blocks, s);
