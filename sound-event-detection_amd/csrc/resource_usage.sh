@@ -1,7 +1,9 @@
 #!/bin/bash
 # Prints one line per kernel of a .hip file: registers, spills, scratch, occupancy (hipcc resource remarks).
+# usage: resource_usage.sh [file.hip] [extra hipcc flags]
 f=${1:-sed_frontend.hip}
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I../../include -c "$f" -o /dev/null \
+shift
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I../../include "$@" -c "$f" -o /dev/null \
   -Rpass-analysis=kernel-resource-usage 2>&1 | python3 -c '
 import re,sys
 cur=None
@@ -15,7 +17,7 @@ for line in sys.stdin:
     else:
         k,v=t.split(":",1)
         k=k.strip()
-        if k in ("VGPRs","AGPRs","TotalSGPRs","ScratchSize [bytes/lane]","Occupancy [waves/SIMD]","VGPRs Spill","SGPRs Spill"):
+        if k in ("VGPRs","AGPRs","TotalSGPRs","ScratchSize [bytes/lane]","Occupancy [waves/SIMD]","VGPRs Spill","SGPRs Spill","LDS Size [bytes/block]"):
             cur+=f" {k.split()[0]}={v.strip()}"
 if cur: print(cur)
 '

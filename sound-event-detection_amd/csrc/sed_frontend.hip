@@ -16,7 +16,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <mutex>
 #include <new>
+#include <utility>
+#include <vector>
 
 #include "sed_hip.h"
 #include "tables.h"
@@ -27,67 +31,50 @@ using Geo512 = Geo<16, 16, 8, 12>;
 using Geo1024 = Geo<32, 16, 16, 12>;
 using Geo2048 = Geo<32, 32, 16, 4>;
 
+#if defined(SED_TIMELINE) || defined(SED_X_MASK)
+#define SED_DIAGNOSTIC_BUILD 1  // diagnostic builds read SED_DEBUG_WAVES from the environment
+#endif
+
 constexpr int kMaxMelSets = 4;
 constexpr int kMelBurst = 8;    // steps of 4 bins whose MFMA operands are fetched from LDS in one burst
 constexpr int kPartStride = 20;  // floats between the partial sums of consecutive positions: [frame][filter] + pad (4*odd: bank spread)
+constexpr int kMaxSpanBlocks = 32;  // 1 KB blocks of a staged span: (FPW - 1) * hop + n_fft <= 4 * 2048 samples
 
-// Timing ablations: build with -DSED_ABLATION and set SED_DEBUG_SKIP=<mask> to leave phases of the streaming loop
-// out (results are then garbage).  In normal builds the tests below fold to false.
-#if defined(SED_ABLATION) || defined(SED_STAMPS)
-#define SED_DIAGNOSTIC_BUILD 1  // diagnostic builds read SED_DEBUG_WAVES / SED_DEBUG_CHUNK / SED_DEBUG_SKIP from the environment
-#endif
-#ifdef SED_ABLATION
-#define SED_SKIP(p, bit) (((p).skip & (bit)) != 0)
+// Compile-time ablations for timing experiments (results are then garbage): -DSED_X_MASK=<bits>.
+#if defined(SED_X_MASK)
+#define SED_SKIP(bit) (((SED_X_MASK) & (bit)) != 0)
 #else
-#define SED_SKIP(p, bit) false
+#define SED_SKIP(bit) false
 #endif
 
+// The tables of a plan as one image in global memory, laid out exactly as the kernel keeps them in LDS (so the
+// prologue is a straight 16-byte copy): [window | inter-stage twiddles | split twiddles] (lane-major, see Geo), then
+// for the fused kernel [mel weights | per-lane B-operand offsets | per-lane gather words | affine | 4 zeros].
+struct ImageLayout {
+  int32_t off_tw1, off_tw2, off_mela, off_boff, off_gw, off_aff, off_zero, floats_spec, floats_fused;
+};
 
 struct FrontParams {
   const void* pcm;
   float* out;
+  const float* image;
   int64_t L, pcm_stride, out_stride_b;
   int32_t T, hop, pad_left, pad_mode, pcm_kind;
   float pcm_div;
   int32_t n_mels, log_kind, affine;
   float amin, db_offset, ln_offset;
   // per-frame conditioning of the Kaldi flavour: DC removal over win_length samples and pre-emphasis
-  int32_t remove_dc, win_length, pre_off;  // pre_off: floats from the start of the wave region to its partial-sum scratch
+  int32_t remove_dc, win_length, pre_off;  // pre_off: floats from the start of the wave region to its pooling scratch
   float preemph, inv_win_length;
-  int32_t chunk_frames, chunks_per_clip, total_chunks;
-  // per-wave LDS region, in floats: [exchange rows | power rows, then mel partial sums at part_off]; frames at clip
-  // edges (padding) or in unaligned clips are first staged here, span floats for FPW frames
+  // work units: a group = FPW consecutive frames of one clip
+  int32_t groups_per_clip, total_groups;
+  // per-wave LDS region, in floats: [staged span, then exchange rows, then power rows | mel partial sums at part_off]
   int32_t span, span_blocks, dma, early, wave_floats, part_off;
-  // LDS carve of the shared tables, in floats
-  int32_t off_win, off_tw1, off_tw2, off_mela, off_melbase, off_quadpos, off_boff, off_gw, off_aff, off_zero, off_wave;
+  int32_t image_floats, off_queue, off_wave;
+  ImageLayout im;
   int32_t mel_sets, mel_u, mel_maxpos, n_quads, out_vec;
-  unsigned long long* stamps;  // diagnostic build only: [wave][8] cycle sums
-  int32_t skip;  // diagnostic: bit k set = phase k of the streaming loop is not executed (timing ablations only)
-  const float* window;
-  const cplx* tw1;
-  const cplx* tw2;
-  const float* mela;
-  const int32_t* melbase;
-  const int32_t* quadpos;
-  const float* aff_scale;
-  const float* aff_shift;
+  unsigned long long* stamps;  // SED_TIMELINE builds only
 };
-
-// In-kernel phase timing (diagnostic build, -DSED_STAMPS): cycles per phase summed per wavefront.
-#ifdef SED_STAMPS
-#define SED_STAMP_DECL unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_t = sed_stamp();
-#define SED_STAMP(k) { const unsigned long long t_ = sed_stamp(); st_acc[k] += t_ - st_t; st_t = t_; }
-__device__ __forceinline__ unsigned long long sed_stamp() {
-  unsigned long long t;
-  __builtin_amdgcn_sched_barrier(0);
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-  __builtin_amdgcn_sched_barrier(0);
-  return t;
-}
-#else
-#define SED_STAMP_DECL
-#define SED_STAMP(k)
-#endif
 
 // Orders LDS accesses of different lanes of ONE wavefront.  The hardware executes a wavefront's LDS operations in
 // the order they were issued, so no wait is needed: this only stops the compiler from moving memory operations
@@ -188,22 +175,23 @@ __device__ __forceinline__ void stage_span(const FrontParams& p, float* dst, int
 }
 
 // Interior spans of 16-byte-aligned fp32 clips go from global memory straight to LDS (no registers in between),
-// 16 bytes per lane and 1 KB per instruction, every sample fetched once per group of frames.  The last block
-// re-reads the span's final bytes (clamped source) and lands past the span.  Completion: vmcnt.
+// 16 bytes per lane and 1 KB per instruction, every sample fetched once per group of frames.  The caller has checked
+// that span_blocks * 256 samples from s0 on lie inside the clip, so the last block simply lands past the span.
+// One per-lane address serves four instructions (the 13-bit instruction offset moves the source and the LDS
+// destination together).  Completion: vmcnt.
 __device__ __forceinline__ void stage_span_dma(const FrontParams& p, float* dst, int64_t b, int64_t s0, int lane) {
-  const float* src = (const float*)p.pcm + b * p.pcm_stride + s0;
-  for (int k = 0; k < p.span_blocks; ++k)
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + min(256 * k + 4 * lane, p.span - 4)),
-                                     (__attribute__((address_space(3))) void*)(dst + 256 * k), 16, 0, 0);
-}
-
-// Gather word of output lane `ol` (0..127): lane 4*quad + frame sums the partial sums of its quad for its frame.
-// bits 0-15: float offset of the first partial sum in the partial-sum region, bits 16-20: number of positions.
-__device__ __forceinline__ int mel_gather_word(const FrontParams& p, const int32_t* quadpos, int ol) {
-  const int q = ol >> 2, jj = ol & 3;
-  if (q >= p.n_quads) return 0;
-  const int info = quadpos[q];
-  return ((info & 0xffff) * kPartStride + jj * 4) | ((info >> 16) << 16);
+  const float* src = (const float*)p.pcm + b * p.pcm_stride + s0 + 4 * lane;
+  static_for<0, kMaxSpanBlocks / 4>([&](auto Qf) {
+    constexpr int q = decltype(Qf)::value;
+    if (4 * q < p.span_blocks) {  // wave-uniform
+      const auto* gs = (const __attribute__((address_space(1))) void*)(src + 1024 * q);
+      auto* ld = (__attribute__((address_space(3))) void*)(dst + 1024 * q);
+      __builtin_amdgcn_global_load_lds(gs, ld, 16, 0, 0);
+      if (4 * q + 1 < p.span_blocks) __builtin_amdgcn_global_load_lds(gs, ld, 16, 1024, 0);
+      if (4 * q + 2 < p.span_blocks) __builtin_amdgcn_global_load_lds(gs, ld, 16, 2048, 0);
+      if (4 * q + 3 < p.span_blocks) __builtin_amdgcn_global_load_lds(gs, ld, 16, 3072, 0);
+    }
+  });
 }
 
 // Mel projection of 4 frames (power rows prow0 + j*PITCH, j = 0..3) on the matrix pipe.
@@ -216,62 +204,63 @@ __device__ __forceinline__ void mel_mfma_4frames(const FrontParams& p, const int
   asm volatile("" : "+v"(lane));  // keeps the per-lane table reads inside the streaming loop instead of pinning registers
   const int blk = lane >> 2, j = lane & 3;
   const int U = p.mel_u;
-  for (int s = 0; s < (SED_SKIP(p, 32) ? 0 : p.mel_sets); ++s) {
-    const float* bp = prow0 + boffL[s * 64 + lane];
-    const float* ap = mela + ((size_t)s * (U + 1) * 64 + lane) * 4;
-    v4 acc = v4{0.0f, 0.0f, 0.0f, 0.0f};
-    for (int u0 = 0; u0 < U; u0 += kMelBurst) {
-      // one burst of LDS reads for up to kMelBurst steps of 4 bins, then the instructions, two steps per
-      // (wave-uniform) test
-      v4 a[kMelBurst], b[kMelBurst];
-      static_for<0, kMelBurst / 2>([&](auto Pf) {
-        constexpr int k = 2 * decltype(Pf)::value;
-        if (u0 + k < U) {  // wave-uniform: pairs of steps past the end are not fetched at all
-          a[k] = ld4(ap + 256 * (u0 + k));
-          b[k] = ld4(bp + 4 * (u0 + k));
-          a[k + 1] = ld4(ap + 256 * (u0 + k + 1));  // u0 + k + 1 == U reads the all-zero weights
-          b[k + 1] = ld4(bp + 4 * min(u0 + k + 1, U - 1));
-        }
-      });
-      SED_SCHED_FENCE();  // the whole burst is in flight before the first instruction waits for its operands
-      static_for<0, kMelBurst / 2>([&](auto Pf) {
-        constexpr int k = 2 * decltype(Pf)::value;
-        if (u0 + k < U) {
-          acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[k].x, b[k].x, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[k].y, b[k].y, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[k].z, b[k].z, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[k].w, b[k].w, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[k + 1].x, b[k + 1].x, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[k + 1].y, b[k + 1].y, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[k + 1].z, b[k + 1].z, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[k + 1].w, b[k + 1].w, acc, 0, 0, 0);
-        }
-      });
+  int boff[kMaxMelSets];
+  static_for<0, kMaxMelSets>([&](auto Sf) { boff[decltype(Sf)::value] = boffL[decltype(Sf)::value * 64 + lane]; });
+  static_for<0, kMaxMelSets>([&](auto Sf) {
+    constexpr int s = decltype(Sf)::value;
+    if (s < (SED_SKIP(32) ? 0 : p.mel_sets)) {
+      const float* bp = prow0 + boff[s];
+      const float* ap = mela + ((size_t)s * (U + 1) * 64 + lane) * 4;
+      v4 acc = v4{0.0f, 0.0f, 0.0f, 0.0f};
+      for (int u0 = 0; u0 < U; u0 += kMelBurst) {
+        // one burst of LDS reads for up to kMelBurst steps of 4 bins, then the instructions, two steps per
+        // (wave-uniform) test
+        v4 a[kMelBurst], bb[kMelBurst];
+        static_for<0, kMelBurst / 2>([&](auto Pf) {
+          constexpr int k = 2 * decltype(Pf)::value;
+          if (u0 + k < U) {  // wave-uniform: pairs of steps past the end are not fetched at all
+            a[k] = ld4(ap + 256 * (u0 + k));
+            bb[k] = ld4(bp + 4 * (u0 + k));
+            a[k + 1] = ld4(ap + 256 * (u0 + k + 1));  // u0 + k + 1 == U reads the all-zero weights
+            bb[k + 1] = ld4(bp + 4 * min(u0 + k + 1, U - 1));
+          }
+        });
+        SED_SCHED_FENCE();  // the whole burst is in flight before the first instruction waits for its operands
+        static_for<0, kMelBurst / 2>([&](auto Pf) {
+          constexpr int k = 2 * decltype(Pf)::value;
+          if (u0 + k < U) {
+            acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[k].x, bb[k].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[k].y, bb[k].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[k].z, bb[k].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[k].w, bb[k].w, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[k + 1].x, bb[k + 1].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[k + 1].y, bb[k + 1].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[k + 1].z, bb[k + 1].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[k + 1].w, bb[k + 1].w, acc, 0, 0, 0);
+          }
+        });
+      }
+      st4(part + (s * 16 + blk) * kPartStride + j * 4, acc);
     }
-    st4(part + (s * 16 + blk) * kPartStride + j * 4, acc);
-  }
+  });
   wave_phase_fence();
 }
 
 // Round r of the gather: lane 4*q + j sums the partial sums of quad 16 r + q for frame j, takes the log and applies
-// the optional affine.  It then holds 4 consecutive filters of one frame.
+// the optional affine.  It then holds 4 consecutive filters of one frame.  The gather word of a lane holds the float
+// offset of its quad's first partial sum (bits 0-15) and the quad's number of positions (bits 16-20); lanes whose quad
+// has fewer positions than the widest one read a block of zeros instead.
 __device__ __forceinline__ v4 mel_gather_log(const FrontParams& p, const int32_t* gwL, const float* affL,
                                              const float* zero4, const float* part, int r, int lane) {
   asm volatile("" : "+v"(lane));
   const int g = gwL[r * 64 + lane];
   const int npos = g >> 16;
   const float* first = part + (g & 0xffff);
-  v4 sum = v4{0.0f, 0.0f, 0.0f, 0.0f};
-  for (int i0 = 0; i0 < p.mel_maxpos; i0 += 8) {
-    // exactly as many reads as the widest quad has positions (wave-uniform tests); lanes whose quad has fewer read
-    // a block of zeros
-    v4 v[8];
-    static_for<0, 8>([&](auto If) {
-      constexpr int i = decltype(If)::value;
-      v[i] = v4{0.0f, 0.0f, 0.0f, 0.0f};
-      if (i0 + i < p.mel_maxpos) v[i] = ld4((i0 + i < npos) ? first + (i0 + i) * kPartStride : zero4);
-    });
-    sum += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+  v4 sum = ld4(first);  // every quad has at least one position
+  for (int i0 = 1; i0 < p.mel_maxpos; i0 += 2) {  // wave-uniform trip count
+    const v4 x = ld4(i0 < npos ? first + i0 * kPartStride : zero4);
+    const v4 y = ld4(i0 + 1 < npos ? first + (i0 + 1) * kPartStride : zero4);
+    sum += x + y;
   }
   v4 val = sum;
   if (p.log_kind == SED_LOG_DB10) {
@@ -312,91 +301,74 @@ __device__ __forceinline__ void mel_store(const FrontParams& p, float* dst, v4 v
   }
 }
 
+// Work distribution.  A group is FPW consecutive frames of one clip.  Every workgroup owns a contiguous range of
+// groups (so a CU streams through contiguous PCM); its wavefronts take them one at a time from a counter in LDS.
+// The hardware issues instructions oldest-wavefront-first, so wavefronts with equal static shares finish far
+// apart (measured: the first after 58 % of the kernel time) and the last ones run on a nearly empty CU; with the
+// queue they all stay busy until the range is drained.  The span of the next group is ordered as soon as the current
+// one's power rows are consumed, whichever clip it belongs to.
 template <class G, bool MAG, bool SPEC_OUT, bool PRE, bool I16>
 __global__ void __launch_bounds__(G::WAVES * 64) __attribute__((amdgpu_waves_per_eu(G::WAVES / 4, G::WAVES / 4)))
 stft_mel_kernel(const FrontParams p) {
   extern __shared__ __align__(16) float smem[];
+#ifdef SED_TIMELINE
+  const unsigned long long tl_start = __builtin_amdgcn_s_memrealtime();
+#endif
   const int NT = blockDim.x;  // up to G::WAVES wavefronts; the host launches fewer when LDS is short
   const int tid = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: chunk bookkeeping stays scalar
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: group bookkeeping stays scalar
   const int lane = tid & 63;
   const int fi = lane / G::LPF, l = lane % G::LPF;
+  const int wg_waves = NT >> 6;
 
-  float* winL = smem + p.off_win;
-  float* tw1L = smem + p.off_tw1;
-  float* tw2L = smem + p.off_tw2;
-  float* melaL = smem + p.off_mela;
-  int32_t* melbaseL = (int32_t*)(smem + p.off_melbase);
-  int32_t* quadposL = (int32_t*)(smem + p.off_quadpos);
-  int32_t* boffL = (int32_t*)(smem + p.off_boff);
-  int32_t* gwL = (int32_t*)(smem + p.off_gw);
-  float* affL = smem + p.off_aff;
-  float* zeroL = smem + p.off_zero;
+  float* winL = smem;
+  float* tw1L = smem + p.im.off_tw1;
+  float* tw2L = smem + p.im.off_tw2;
+  float* melaL = smem + p.im.off_mela;
+  int32_t* boffL = (int32_t*)(smem + p.im.off_boff);
+  int32_t* gwL = (int32_t*)(smem + p.im.off_gw);
+  float* affL = smem + p.im.off_aff;
+  float* zeroL = smem + p.im.off_zero;
+  int* qhead = (int*)(smem + p.off_queue);
   float* X = smem + p.off_wave + wave * p.wave_floats;
 
-  // tables: natural order in global memory, lane-major (see Geo) in LDS; padding entries are never read
-  for (int i = tid; i < G::NFFT; i += NT) winL[win_slot<G>(i)] = p.window[i];
-  for (int i = tid; i < G::R1 * G::R2; i += NT) {
-    const cplx w = p.tw1[i];
-    float* d = tw1L + tw1_slot<G>(i / G::R2, i % G::R2);
-    d[0] = w.x; d[1] = w.y;
-  }
-  for (int i = tid; i < G::LPF * (G::SLOTS + 1); i += NT) {
-    const int t = i / G::LPF, l = i % G::LPF;
-    const cplx w = t < G::SLOTS ? p.tw2[i] : cplx{0.0f, 0.0f};  // the odd slot count is padded: slots are read in pairs
-    float* d = tw2L + tw2_slot<G>(t, l);
-    d[0] = w.x; d[1] = w.y;
-  }
-  if constexpr (!SPEC_OUT) {
-    for (int i = tid; i < p.mel_sets * (p.mel_u + 1) * 256; i += NT) melaL[i] = p.mela[i];
-    if (p.affine)
-      for (int i = tid; i < 256; i += NT) {
-        const int m = i & 127;
-        affL[i] = m < p.n_mels ? (i < 128 ? p.aff_scale[m] : p.aff_shift[m]) : 0.0f;
-      }
-    if (tid < 4) zeroL[tid] = 0.0f;
-    for (int i = tid; i < p.mel_sets * 16; i += NT) melbaseL[i] = p.melbase[i];
-    for (int i = tid; i < p.n_quads; i += NT) quadposL[i] = p.quadpos[i];
-  }
+  // tables: the plan's image is already in LDS order
+  for (int i = 4 * tid; i < p.image_floats; i += 4 * NT) st4(smem + i, ld4(p.image + i));
+  if (tid == 0) *qhead = wg_waves;  // wavefront w starts with group w of the range
   __syncthreads();
-  if constexpr (!SPEC_OUT) {  // per-lane constants of the mel stage: [set][lane] B-operand offsets, [r][lane] gather words
-    for (int i = tid; i < kMaxMelSets * 64; i += NT) {
-      const int s = i >> 6, ln = i & 63;
-      boffL[i] = (s < p.mel_sets) ? (ln & 3) * G::PP + melbaseL[s * 16 + (ln >> 2)] : 0;
-    }
-    for (int i = tid; i < 2 * 64; i += NT) gwL[i] = mel_gather_word(p, quadposL, i);
-    __syncthreads();
-  }
 
-  SED_STAMP_DECL
-  const int wg_waves = NT >> 6, n_waves = gridDim.x * wg_waves;
-  for (int chunk = blockIdx.x * wg_waves + wave; chunk < p.total_chunks; chunk += n_waves) {
-    const int b = chunk / p.chunks_per_clip;
-    const int f_begin = (chunk - b * p.chunks_per_clip) * p.chunk_frames;
-    const int f_end = min(p.T, f_begin + p.chunk_frames);
-    // Streaming state of the chunk.
-    //  staged : the span of the group about to be processed is already on its way into X (issued by the previous
-    //           iteration as soon as its power rows were consumed, so most of the fetch latency is hidden)
-    //  held   : log-mel values of the previous group, stored one iteration late: vmcnt counts loads and stores in
-    //           order, and a store issued just before the wait for the span would put its own latency on the path
-    constexpr int kGroups = G::FPW / 4;
+  const int g_begin = (int)((int64_t)p.total_groups * blockIdx.x / gridDim.x);
+  const int g_end = (int)((int64_t)p.total_groups * (blockIdx.x + 1) / gridDim.x);
+#ifdef SED_TIMELINE
+  const unsigned long long tl_loop = __builtin_amdgcn_s_memrealtime();
+#endif
+  constexpr int kGroups = G::FPW / 4;
+  int gi = g_begin + wave;
+  if (gi < g_end) {
+    int b = gi / p.groups_per_clip;
+    int f0 = (gi - b * p.groups_per_clip) * G::FPW;
+    // staged : the span of the group about to be processed is already on its way into X
+    // held   : log-mel values of the previous group, stored one iteration late: vmcnt counts loads and stores in
+    //          order, and a store issued just before the wait for the span would put its own latency on the path
     bool staged = false, held = false;
     v4 hval[kGroups][2];
     float* hdst = nullptr;
     int hvalid = 0;
-    for (int f0 = f_begin; f0 < f_end; f0 += G::FPW) {
+    while (true) {
+      // take the next group now; the answer is needed when its span is ordered, half an iteration from here
+      int taken = 0;
+      if (lane == 0) taken = atomicAdd(qhead, 1);
       const int64_t s0 = (int64_t)f0 * p.hop - p.pad_left;
       LaneState<G> st;
       if (!staged) {
-        if (!I16 && p.dma && s0 >= 0 && s0 + p.span <= p.L) {
-          if (!SED_SKIP(p, 1)) stage_span_dma(p, X, b, s0, lane);
+        if (!I16 && p.dma && s0 >= 0 && s0 + 256 * p.span_blocks <= p.L) {
+          if (!SED_SKIP(1)) stage_span_dma(p, X, b, s0, lane);
         } else {
           stage_span<I16>(p, X, b, s0, p.span, lane);
         }
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       wave_phase_fence();
-      SED_STAMP(0)
       if constexpr (!SPEC_OUT) {
         if (held) {
           static_for<0, kGroups>([&](auto Gf) {
@@ -422,9 +394,8 @@ stft_mel_kernel(const FrontParams p) {
         lane_stage1<G>(st, SrcF32{X + fi * p.hop}, winL, tw1L, l);
       }
       wave_phase_fence();
-      SED_STAMP(1)
       float* xfr = X + fi * G::XFR;
-      if (!SED_SKIP(p, 8)) {
+      if (!SED_SKIP(8)) {
         lane_xwrite<G, 0>(st, xfr, l);
         wave_phase_fence();
         lane_xread<G, 0>(st, xfr, l);
@@ -433,14 +404,19 @@ stft_mel_kernel(const FrontParams p) {
         wave_phase_fence();
         lane_xread<G, 1>(st, xfr, l);
         wave_phase_fence();
+      } else {
+        static_for<0, G::R2>([&](auto Nf) { st.p[decltype(Nf)::value] = st.y[0][decltype(Nf)::value]; st.q[decltype(Nf)::value] = st.y[0][G::R1 - 1 - decltype(Nf)::value]; });
       }
-      SED_STAMP(3)
       float* pw = X + fi * G::PP;
-      if (!SED_SKIP(p, 16)) lane_stage2_power<G, MAG>(st, pw, tw2L, l);
+      lane_stage2_power<G, MAG>(st, pw, tw2L, l);
       for (int k = G::NBINS + l; k < G::PP; k += G::LPF) pw[k] = 0.0f;  // row padding read (with zero weight) by the mel stage
       wave_phase_fence();
-      SED_STAMP(4)
-      const int nvalid = min(G::FPW, f_end - f0);
+      const int nvalid = min(G::FPW, p.T - f0);
+      // the group after this one: the one just taken from the queue
+      gi = g_begin + __builtin_amdgcn_readfirstlane(taken);
+      const bool more = gi < g_end;
+      const int nb = gi / p.groups_per_clip;
+      const int nf0 = (gi - nb * p.groups_per_clip) * G::FPW;
       staged = false;
       if constexpr (SPEC_OUT) {
         float* dst = p.out + (int64_t)b * p.out_stride_b + (int64_t)f0 * G::NBINS;
@@ -453,25 +429,26 @@ stft_mel_kernel(const FrontParams p) {
           mel_mfma_4frames(p, boffL, X + 4 * g * G::PP, melaL, part, lane);
           if constexpr (g == kGroups - 1) {
             // the power rows are consumed: the next group's span may land on them while the gather runs
-            const int64_t s1 = s0 + (int64_t)G::FPW * p.hop;
-            if (!I16 && p.early && f0 + G::FPW < f_end && s1 >= 0 && s1 + p.span <= p.L && !SED_SKIP(p, 1)) {
-              stage_span_dma(p, X, b, s1, lane);
+            const int64_t s1 = (int64_t)nf0 * p.hop - p.pad_left;
+            if (!I16 && p.early && more && s1 >= 0 && s1 + 256 * p.span_blocks <= p.L && !SED_SKIP(1)) {
+              stage_span_dma(p, X, nb, s1, lane);
               staged = true;
             }
           }
-          if (!SED_SKIP(p, 64)) {
+          if (!SED_SKIP(64)) {
             hval[g][0] = mel_gather_log(p, gwL, affL, zeroL, part, 0, lane);
             if (p.n_quads > 16) hval[g][1] = mel_gather_log(p, gwL, affL, zeroL, part, 1, lane);
           }
           wave_phase_fence();
         });
-        held = !SED_SKIP(p, 64);
+        held = !SED_SKIP(64);
         hdst = p.out + (int64_t)b * p.out_stride_b + (int64_t)f0 * p.n_mels;
         hvalid = nvalid;
-        SED_STAMP(5)
       }
       wave_phase_fence();
-      SED_STAMP(6)
+      if (!more) break;
+      b = nb;
+      f0 = nf0;
     }
     if constexpr (!SPEC_OUT) {
       if (held) {
@@ -483,9 +460,13 @@ stft_mel_kernel(const FrontParams p) {
       }
     }
   }
-#ifdef SED_STAMPS
-  if (lane == 0 && p.stamps)
-    for (int k = 0; k < 8; ++k) p.stamps[(size_t)(blockIdx.x * wg_waves + wave) * 8 + k] = st_acc[k];
+#ifdef SED_TIMELINE
+  if (lane == 0 && p.stamps) {
+    unsigned long long* o = p.stamps + (size_t)(blockIdx.x * wg_waves + wave) * 4;
+    o[0] = tl_start; o[1] = tl_loop; o[2] = __builtin_amdgcn_s_memrealtime();
+    unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    o[3] = ((unsigned long long)xcc << 32);
+  }
 #endif
 }
 
@@ -570,18 +551,16 @@ struct sed_plan {
   int geo = 1;  // 0: 512, 1: 1024, 2: 2048
   std::vector<double> window_host;
   std::vector<float> melW_host;  // [F][M]
-  float* d_window = nullptr;     // 0.5 * window, fp32
-  cplx* d_tw1 = nullptr;
-  cplx* d_tw2 = nullptr;
-  // banded mel matrix scheduled for the matrix pipe (fused kernel)
-  float* d_mela = nullptr;
-  int32_t* d_melbase = nullptr;
-  int32_t* d_quadpos = nullptr;
+  // every table of the fused / spectrogram kernels in LDS order (see ImageLayout)
+  std::vector<float> image_host;
+  float* d_image = nullptr;
+  ImageLayout im{};
   int mel_sets = 0, mel_u = 0, mel_maxpos = 0, n_quads = 0;
   // banded mel matrix scheduled over 16 lanes (mel_rows_kernel)
   MelEntry* d_meta16 = nullptr;
   float* d_melw16 = nullptr;
   int mel_slots16 = 0, mel_wcount16 = 0;
+  std::vector<float> scale_host, shift_host;
   float* d_scale = nullptr;
   float* d_shift = nullptr;
   bool affine = false;
@@ -604,19 +583,70 @@ static int upload(T** dst, const std::vector<T>& src) {
   return SED_OK;
 }
 
-static int row_pitch_of(int geo) { return geo == 0 ? Geo512::PP : geo == 1 ? Geo1024::PP : Geo2048::PP; }
+static inline int round4(int v) { return (v + 3) & ~3; }
+static inline int round64(int v) { return (v + 63) & ~63; }
 
-static int upload_mel(sed_plan* pl) {
+// Builds the LDS image of a plan: window (with the factor 1/2 of the real-FFT split), twiddles, and the mel
+// projection scheduled for the matrix pipe with its per-lane constants.
+template <class G>
+static void build_image(sed_plan* pl) {
   const int F = pl->cfg.n_fft / 2 + 1, M = pl->cfg.n_mels;
-  const MelMfmaSchedule sc = schedule_mel_mfma(pl->melW_host, F, M, row_pitch_of(pl->geo), kMaxMelSets);
+  const MelMfmaSchedule sc = schedule_mel_mfma(pl->melW_host, F, M, G::PP, kMaxMelSets);
   pl->mel_sets = sc.sets;
   pl->mel_u = sc.tau / 4;
   pl->mel_maxpos = sc.max_pos;
   pl->n_quads = sc.n_quads;
-  int rc = upload(&pl->d_mela, sc.a);
-  if (!rc) rc = upload(&pl->d_melbase, sc.base);
-  if (!rc) rc = upload(&pl->d_quadpos, sc.quadpos);
+  ImageLayout im{};
+  int off = G::WIN_FLOATS;
+  im.off_tw1 = off; off += G::TW1_FLOATS;
+  im.off_tw2 = off; off += G::TW2_FLOATS;
+  im.floats_spec = round4(off);
+  off = im.floats_spec;
+  im.off_mela = off; off += (int)sc.a.size();
+  im.off_boff = off; off += kMaxMelSets * 64;
+  im.off_gw = off; off += 2 * 64;
+  im.off_aff = off; off += 256;
+  im.off_zero = off; off += 4;
+  im.floats_fused = round4(off);
+  std::vector<float> img(im.floats_fused, 0.0f);
+  for (int i = 0; i < G::NFFT; ++i) img[win_slot<G>(i)] = (float)(0.5 * pl->window_host[i]);
+  const std::vector<cplx> t1 = build_tw1<G>();
+  for (int k1 = 0; k1 < G::R1; ++k1)
+    for (int n2 = 0; n2 < G::R2; ++n2) {
+      img[im.off_tw1 + tw1_slot<G>(k1, n2)] = t1[k1 * G::R2 + n2].x;
+      img[im.off_tw1 + tw1_slot<G>(k1, n2) + 1] = t1[k1 * G::R2 + n2].y;
+    }
+  const std::vector<cplx> t2 = build_tw2<G>();
+  for (int t = 0; t < G::SLOTS; ++t)  // (the odd slot count is padded with zeros: slots are read in pairs)
+    for (int l = 0; l < G::LPF; ++l) {
+      img[im.off_tw2 + tw2_slot<G>(t, l)] = t2[t * G::LPF + l].x;
+      img[im.off_tw2 + tw2_slot<G>(t, l) + 1] = t2[t * G::LPF + l].y;
+    }
+  std::copy(sc.a.begin(), sc.a.end(), img.begin() + im.off_mela);
+  int32_t* boff = reinterpret_cast<int32_t*>(img.data() + im.off_boff);
+  for (int s = 0; s < kMaxMelSets; ++s)
+    for (int ln = 0; ln < 64; ++ln) boff[s * 64 + ln] = s < sc.sets ? (ln & 3) * G::PP + sc.base[s * 16 + (ln >> 2)] : 0;
+  int32_t* gw = reinterpret_cast<int32_t*>(img.data() + im.off_gw);
+  for (int ol = 0; ol < 128; ++ol) {  // gather word of output lane ol: lane 4*quad + frame sums the partial sums of its quad
+    const int q = ol >> 2, jj = ol & 3;
+    // lanes without a quad read the zero block: offset of a position that holds finite values, zero positions beyond the first
+    gw[ol] = q < sc.n_quads ? (((sc.quadpos[q] & 0xffff) * kPartStride + jj * 4) | ((sc.quadpos[q] >> 16) << 16)) : (1 << 16);
+  }
+  for (int m = 0; m < 128; ++m) {
+    img[im.off_aff + m] = (pl->affine && m < M) ? pl->scale_host[m] : 0.0f;
+    img[im.off_aff + 128 + m] = (pl->affine && m < M) ? pl->shift_host[m] : 0.0f;
+  }
+  pl->im = im;
+  pl->image_host.swap(img);
+}
+
+static int upload_tables(sed_plan* pl) {
+  if (pl->geo == 0) build_image<Geo512>(pl);
+  else if (pl->geo == 1) build_image<Geo1024>(pl);
+  else build_image<Geo2048>(pl);
+  int rc = upload(&pl->d_image, pl->image_host);
   if (rc) return rc;
+  const int F = pl->cfg.n_fft / 2 + 1, M = pl->cfg.n_mels;
   MelSchedule s16 = schedule_mel(pl->melW_host, F, M, 16);
   pl->mel_slots16 = s16.slots;
   pl->mel_wcount16 = (int)s16.weights.size();
@@ -707,8 +737,6 @@ extern "C" int sed_plan_create(const sed_frontend_cfg* cfg, sed_plan** out) {
 
   pl->window_host = build_window(cfg->n_fft, cfg->win_length, cfg->win_align == SED_WIN_LEFT,
                                  cfg->window_kind == SED_WINDOW_HANN_SYMMETRIC);
-  std::vector<float> wh(cfg->n_fft);
-  for (int i = 0; i < cfg->n_fft; ++i) wh[i] = (float)(0.5 * pl->window_host[i]);
   pl->melW_host = build_mel(cfg->mel_kind, cfg->sample_rate, cfg->n_fft, cfg->n_mels, cfg->fmin, cfg->fmax);
   pl->db_offset = (float)(10.0 * std::log10(std::max((double)cfg->amin, (double)cfg->ref)));
 
@@ -724,12 +752,7 @@ extern "C" int sed_plan_create(const sed_frontend_cfg* cfg, sed_plan** out) {
     pl->pcm_div3 = same;
   }
 
-  rc = upload(&pl->d_window, wh);
-  if (!rc) rc = geo == 0 ? upload(&pl->d_tw1, build_tw1<Geo512>())
-                : geo == 1 ? upload(&pl->d_tw1, build_tw1<Geo1024>()) : upload(&pl->d_tw1, build_tw1<Geo2048>());
-  if (!rc) rc = geo == 0 ? upload(&pl->d_tw2, build_tw2<Geo512>())
-                : geo == 1 ? upload(&pl->d_tw2, build_tw2<Geo1024>()) : upload(&pl->d_tw2, build_tw2<Geo2048>());
-  if (!rc) rc = upload_mel(pl);
+  rc = upload_tables(pl);
   if (rc) { sed_plan_destroy(pl); return rc; }
   *out = pl;
   return SED_OK;
@@ -737,8 +760,7 @@ extern "C" int sed_plan_create(const sed_frontend_cfg* cfg, sed_plan** out) {
 
 extern "C" void sed_plan_destroy(sed_plan* pl) {
   if (!pl) return;
-  void* bufs[] = {pl->d_window, pl->d_tw1, pl->d_tw2, pl->d_mela, pl->d_melbase, pl->d_quadpos, pl->d_meta16,
-                  pl->d_melw16, pl->d_scale, pl->d_shift};
+  void* bufs[] = {pl->d_image, pl->d_meta16, pl->d_melw16, pl->d_scale, pl->d_shift};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   delete pl;
@@ -785,7 +807,7 @@ extern "C" int sed_plan_set_mel_weights(sed_plan* pl, const float* melW) {
   if (rc) return rc;
   SED_HIP_TRY(hipDeviceSynchronize());
   std::memcpy(pl->melW_host.data(), melW, pl->melW_host.size() * sizeof(float));
-  return upload_mel(pl);
+  return upload_tables(pl);
 }
 
 extern "C" int sed_plan_set_affine(sed_plan* pl, const float* scale, const float* shift) {
@@ -794,15 +816,16 @@ extern "C" int sed_plan_set_affine(sed_plan* pl, const float* scale, const float
   if (rc) return rc;
   SED_HIP_TRY(hipDeviceSynchronize());
   pl->affine = scale != nullptr;
-  if (!scale) return SED_OK;
   const int M = pl->cfg.n_mels;
-  rc = upload(&pl->d_scale, std::vector<float>(scale, scale + M));
-  if (rc) return rc;
-  return upload(&pl->d_shift, std::vector<float>(shift, shift + M));
+  if (scale) {
+    pl->scale_host.assign(scale, scale + M);
+    pl->shift_host.assign(shift, shift + M);
+    rc = upload(&pl->d_scale, pl->scale_host);
+    if (!rc) rc = upload(&pl->d_shift, pl->shift_host);
+    if (rc) return rc;
+  }
+  return upload_tables(pl);
 }
-
-static inline int round4(int v) { return (v + 3) & ~3; }
-static inline int round64(int v) { return (v + 63) & ~63; }
 
 template <class G, bool MAG, bool SPEC_OUT, bool PRE_ = false>
 static int launch_front(const sed_plan* pl, FrontParams p, int64_t B, hipStream_t stream) {
@@ -810,24 +833,18 @@ static int launch_front(const sed_plan* pl, FrontParams p, int64_t B, hipStream_
   // per-wave LDS region
   p.span = round4((G::FPW - 1) * p.hop + G::NFFT);
   p.span_blocks = (p.span + 255) / 256;
+  if (p.span_blocks > kMaxSpanBlocks) return SED_ERR_BAD_ARG;
   p.part_off = G::FPW * G::PP;
   p.early = p.dma && !SPEC_OUT && 256 * p.span_blocks <= p.part_off;  // the span may land while the partial sums are in use
   const int part_floats = SPEC_OUT ? 0 : p.mel_sets * 16 * kPartStride;
   p.pre_off = 256 * p.span_blocks;  // behind the staged span: FPW frames x LPF partial sums (Kaldi DC removal)
   p.wave_floats = round64(std::max(std::max(256 * p.span_blocks + (PRE ? 64 : 0), G::FPW * G::XFR), p.part_off + part_floats));
-  // shared tables
-  int off = 0;
-  p.off_win = off; off += G::WIN_FLOATS;
-  p.off_tw1 = off; off += G::TW1_FLOATS;
-  p.off_tw2 = off; off += G::TW2_FLOATS;
-  p.off_mela = off; off += SPEC_OUT ? 0 : p.mel_sets * (p.mel_u + 1) * 256;
-  p.off_melbase = off; off += SPEC_OUT ? 0 : round4(p.mel_sets * 16);
-  p.off_quadpos = off; off += SPEC_OUT ? 0 : round4(p.n_quads);
-  p.off_boff = off; off += SPEC_OUT ? 0 : kMaxMelSets * 64;
-  p.off_gw = off; off += SPEC_OUT ? 0 : 2 * 64;
-  p.off_aff = off; off += (SPEC_OUT || !p.affine) ? 0 : 256;
-  p.off_zero = off; off += 4;
-  p.off_wave = round64(off);
+  // shared tables (the plan's image), then the work-queue head, then the wave regions
+  p.im = pl->im;
+  p.image = pl->d_image;
+  p.image_floats = SPEC_OUT ? pl->im.floats_spec : pl->im.floats_fused;
+  p.off_queue = p.image_floats;
+  p.off_wave = round64(p.off_queue + 4);
   // as many wavefronts per workgroup as the geometry allows and LDS holds
   int waves = G::WAVES;
 #ifdef SED_DIAGNOSTIC_BUILD
@@ -837,45 +854,64 @@ static int launch_front(const sed_plan* pl, FrontParams p, int64_t B, hipStream_
   while (waves > 1 && (size_t)(p.off_wave + waves * p.wave_floats) * sizeof(float) > 160 * 1024) --waves;
   const size_t lds_bytes = (size_t)(p.off_wave + waves * p.wave_floats) * sizeof(float);
   if (lds_bytes > 160 * 1024) return SED_ERR_BAD_ARG;
+#ifdef SED_ONLY_BENCH  // diagnostic builds: one instantiation only, seconds to compile
+  if ((p.pcm_kind & ~kPcmDiv3) == SED_PCM_I16) return SED_ERR_BAD_ARG;
+  auto kern = stft_mel_kernel<G, MAG, SPEC_OUT, PRE, false>;
+#else
   auto kern = (p.pcm_kind & ~kPcmDiv3) == SED_PCM_I16 ? stft_mel_kernel<G, MAG, SPEC_OUT, PRE, true>
                                                        : stft_mel_kernel<G, MAG, SPEC_OUT, PRE, false>;
-  SED_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds_bytes));
-  // chunks: runs of consecutive frames of one clip, one wavefront each
-  const int per_cu = std::max(1, std::min(2, (int)((160 * 1024) / lds_bytes)));
-  const int64_t max_waves = (int64_t)pl->num_cus * per_cu * waves;
-  const int64_t total_frames = B * (int64_t)p.T;
-  int64_t cf = (total_frames + max_waves - 1) / max_waves;
-  cf = std::max<int64_t>(cf, 4 * G::FPW);
-  cf = (cf + G::FPW - 1) / G::FPW * G::FPW;
-#ifdef SED_DIAGNOSTIC_BUILD
-  static const int debug_chunk = getenv("SED_DEBUG_CHUNK") ? atoi(getenv("SED_DEBUG_CHUNK")) : 0;
-  if (debug_chunk > 0) cf = debug_chunk;
 #endif
-  cf = std::min<int64_t>(cf, ((int64_t)p.T + G::FPW - 1) / G::FPW * G::FPW);
-  p.chunk_frames = (int32_t)cf;
-  p.chunks_per_clip = (int32_t)((p.T + cf - 1) / cf);
-  const int64_t total_chunks = (int64_t)p.chunks_per_clip * B;
-  if (total_chunks > INT32_MAX / 2) return SED_ERR_BAD_ARG;
-  p.total_chunks = (int32_t)total_chunks;
-  const int blocks = (int)std::min<int64_t>((total_chunks + waves - 1) / waves, (int64_t)pl->num_cus * per_cu);
-#ifdef SED_STAMPS
-  static unsigned long long* d_stamps = nullptr;
-  const size_t n_st = (size_t)blocks * waves * 8;
-  if (!d_stamps) (void)hipMalloc((void**)&d_stamps, 4096 * 8 * 8 * sizeof(unsigned long long));
-  p.stamps = d_stamps;
+  // the dynamic LDS limit is a property of the kernel function, set once per instantiation (per device: the attribute
+  // lives in the device's code object) to the hardware maximum, so that concurrent launches with different sizes
+  // never race on it
+  {
+    static std::mutex mu;
+    static std::vector<std::pair<const void*, int>> done;
+    std::lock_guard<std::mutex> lock(mu);
+    const std::pair<const void*, int> key{reinterpret_cast<const void*>(kern), pl->device};
+    if (std::find(done.begin(), done.end(), key) == done.end()) {
+      SED_HIP_TRY(hipFuncSetAttribute(key.first, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      done.push_back(key);
+    }
+  }
+  // groups of FPW frames; one workgroup per CU, each with a contiguous share of the groups
+  p.groups_per_clip = (p.T + G::FPW - 1) / G::FPW;
+  const int64_t total_groups = (int64_t)p.groups_per_clip * B;
+  if (total_groups > INT32_MAX / 2) return SED_ERR_BAD_ARG;
+  p.total_groups = (int32_t)total_groups;
+  const int blocks = (int)std::min<int64_t>((total_groups + waves - 1) / waves, (int64_t)pl->num_cus);
+#ifdef SED_TIMELINE
+  static unsigned long long* d_tl = nullptr;
+  const size_t n_tl = (size_t)blocks * waves * 4;
+  if (!d_tl) (void)hipMalloc((void**)&d_tl, 8192 * 4 * sizeof(unsigned long long));
+  p.stamps = d_tl;
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(waves * 64), lds_bytes, stream, p);
-  static int calls = 0;
-  if (++calls == 20) {
+  static int tl_calls = 0;
+  if (++tl_calls == 100) {
     (void)hipDeviceSynchronize();
-    std::vector<unsigned long long> h(n_st);
-    (void)hipMemcpy(h.data(), d_stamps, n_st * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-    double sum[8] = {0};
-    for (size_t w = 0; w < n_st / 8; ++w) for (int k = 0; k < 8; ++k) sum[k] += (double)h[w * 8 + k];
-    const char* names[8] = {"wait for the span", "stage 1", "-", "exchange", "stage 2 + power", "mel", "loop end", "-"};
-    double tot = 0; for (int k = 0; k < 8; ++k) tot += sum[k];
-    for (int k = 0; k < 7; ++k) fprintf(stderr, "STAMP %-24s %10.0f cycles/wave  %5.1f%%\n", names[k], sum[k] / (n_st / 8), 100.0 * sum[k] / tot);
-    fprintf(stderr, "STAMP total %10.0f cycles/wave over %zu waves\n", tot / (n_st / 8), n_st / 8);
+    std::vector<unsigned long long> h(n_tl);
+    (void)hipMemcpy(h.data(), d_tl, n_tl * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    unsigned long long t0 = ~0ull, t1 = 0;
+    for (size_t w = 0; w < n_tl / 4; ++w) { t0 = std::min(t0, h[w * 4]); t1 = std::max(t1, h[w * 4 + 2]); }
+    // s_memrealtime ticks at 100 MHz
+    double sum_res = 0, sum_start = 0, sum_end = 0, sum_setup = 0, max_start = 0, min_end = 1e30;
+    double xe[8] = {0}, xmax[8] = {0}; int xn[8] = {0};
+    for (size_t w = 0; w < n_tl / 4; ++w) {
+      const double a = (h[w * 4] - t0) * 0.01, l = (h[w * 4 + 1] - t0) * 0.01, e = (h[w * 4 + 2] - t0) * 0.01;
+      sum_res += e - a; sum_start += a; sum_end += e; sum_setup += l - a;
+      max_start = std::max(max_start, a); min_end = std::min(min_end, e);
+      const int x = (int)((h[w * 4 + 3] >> 32) & 7);
+      xe[x] += e; xmax[x] = std::max(xmax[x], e); ++xn[x];
+    }
+    const double nw = (double)(n_tl / 4);
+    fprintf(stderr, "TIMELINE waves %zu  span %.2f us  mean start %.2f (max %.2f)  mean setup %.2f  mean end %.2f (min %.2f)  mean residency %.2f us\n",
+            n_tl / 4, (t1 - t0) * 0.01, sum_start / nw, max_start, sum_setup / nw, sum_end / nw, min_end, sum_res / nw);
+    for (int x = 0; x < 8; ++x) if (xn[x]) fprintf(stderr, "TIMELINE xcc %d: waves %d mean end %.2f max end %.2f\n", x, xn[x], xe[x] / xn[x], xmax[x]);
+    int hist[20] = {0};
+    for (size_t w = 0; w < n_tl / 4; ++w) { int bb = (int)((h[w * 4 + 2] - t0) * 0.01 / ((t1 - t0) * 0.01) * 20); hist[std::min(bb, 19)]++; }
+    fprintf(stderr, "TIMELINE end-time histogram (20 bins over the span):");
+    for (int bb = 0; bb < 20; ++bb) fprintf(stderr, " %d", hist[bb]);
+    fprintf(stderr, "\n");
   }
   return hip_status(hipGetLastError());
 #else
@@ -920,26 +956,18 @@ static int front_forward(const sed_plan* pl, const void* pcm, int64_t B, int64_t
   p.preemph = c.preemphasis;
   p.win_length = c.win_length;
   p.inv_win_length = 1.0f / (float)c.win_length;
-  p.window = pl->d_window;
-  p.tw1 = pl->d_tw1;
-  p.tw2 = pl->d_tw2;
-  p.mela = pl->d_mela;
-  p.melbase = pl->d_melbase;
-  p.quadpos = pl->d_quadpos;
   p.mel_sets = pl->mel_sets;
   p.mel_u = pl->mel_u;
   p.mel_maxpos = pl->mel_maxpos;
   p.n_quads = pl->n_quads;
-  p.aff_scale = pl->d_scale;
-  p.aff_shift = pl->d_shift;
   p.dma = (c.pcm_kind == SED_PCM_F32) && ((uintptr_t)pcm % 16 == 0) && (pcm_stride % 4 == 0) && (c.hop % 4 == 0) ? 1 : 0;  // n_fft/2: a multiple of 4
   p.out_vec = (c.n_mels % 4 == 0) && ((uintptr_t)out % 16 == 0) && (out_stride_b % 4 == 0) ? 1 : 0;
-#ifdef SED_DIAGNOSTIC_BUILD
-  static const int debug_skip = getenv("SED_DEBUG_SKIP") ? atoi(getenv("SED_DEBUG_SKIP")) : 0;
-  p.skip = debug_skip;
-#endif
   hipStream_t s = (hipStream_t)stream;
   const bool mag = c.spectrum == SED_SPEC_MAGNITUDE;
+#ifdef SED_ONLY_BENCH
+  if (SPEC_OUT || mag || pl->geo != 1 || c.remove_dc || c.preemphasis > 0.0f) return SED_ERR_BAD_ARG;
+  return launch_front<Geo1024, false, false>(pl, p, B, s);
+#endif
   if (c.remove_dc || c.preemphasis > 0.0f) {  // Kaldi framing: power spectrum, fused log-mel output only
     if constexpr (SPEC_OUT) {
       return SED_ERR_BAD_ARG;
