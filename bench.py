@@ -6,14 +6,21 @@
 
 Workload (BASELINE.json configs[1]): HTS-AT front-end, 32 kHz, n_fft 1024, hop 320, 64 mel, 256 clips of 10 s
 per GPU, fp32 PCM resident in HBM.  One step = one pass of the hot path over the rank's batch: the fused
-log-mel kernel, then the detector-side decode of the same 256 streams (median-3 + threshold + run extraction and
-0.6 s gap merge on synthetic 20-frame probabilities) and, with more than one rank, the all-gather of the
-fixed-size event buffers (asynchronous, overlapped with the next step).  Ranks own independent streams
-(weak scaling).  Rank 0 prints one JSON line.
+log-mel kernel, then the detector-side tail of the same 256 streams, sed_amd.sharding.decode_and_exchange (median-3 +
+threshold + run extraction + 0.6 s gap merge on synthetic 20-frame probabilities, the (stream, class, onset, offset)
+records, and with more than one rank the all-gather of the fixed-size record buffers, asynchronous and overlapped
+with the next step).  Everything in the step stays on the device; formatting events as host dictionaries is outside
+it and is timed separately ("decode_with_host_formatting_ms").  Ranks own independent streams (weak scaling).
+Rank 0 prints one JSON line.
+
+`--gpus N` without a torchrun environment starts the N ranks itself (python -m torch.distributed.run as a child
+process, before this process touches the GPU) and relays rank 0's line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,6 +31,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "sound-event-detection_amd"))
 
 SR, CLIP_S, B_PER_GPU = 32000, 10, 256
+EVENT_CAP = 16              # merged events per stream the exchange keeps (a 20-frame trace has at most 10)
 HBM_PEAK_GBS = 8000.0
 PREWARM_S = 0.3
 
@@ -55,11 +63,25 @@ def main():
                     "rehearse the multi-rank control flow on a box with one GPU, together with --one-device)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Not under torchrun: start the ranks as a fresh child process tree (nothing here has touched the GPU yet) and
+        # pass its output through; rank 0 of the children prints the JSON line.
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd).returncode)
 
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s): the JSON line would misreport n_gpus")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device: the hot path has no CPU fallback")
     if args.one_device:
@@ -99,17 +121,17 @@ def main():
         y = fe(x)
         if i is not None:
             k_events[i][1].record()
-        buf = D.threshold_merge_runs(det, 0.5, table, 0.6, "median3")   # (streams, classes, 1 + 2*cap): count, runs
-        if world > 1:
-            # (the gloo rehearsal gathers host copies: gloo's device-tensor path stalls after a few async gathers)
-            src = buf if args.backend == "nccl" else buf.cpu()
-            out, work = sed_amd.sharding.all_gather_events(src, async_op=True)
+        # decode -> records -> all-gather: the same function tests/test_gpu_sharding.py checks against the oracle
+        # (the gloo rehearsal gathers host copies: gloo's device-tensor path stalls after a few async gathers)
+        out, work = sed_amd.sharding.decode_and_exchange(det, table, 0.6, cap=EVENT_CAP, first_stream=rank * B_PER_GPU,
+                                                         async_op=True, host_staging=(args.backend != "nccl"))
+        if work is not None:
             pending.append((out, work))
             say(f"step {i}: gather issued, {len(pending)} pending")
             if len(pending) > 4:
                 pending.pop(0)[1].wait()
                 say(f"step {i}: oldest gather done")
-        return y, buf
+        return y, out
 
     def fence():
         while pending:
@@ -153,6 +175,18 @@ def main():
     value = hours_per_step * args.steps / elapsed
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
 
+    # the full detector decode including what the step leaves out: device -> host copy of the runs and the Python
+    # formatting of the reference's (onsets, offsets) arrays for 256 streams
+    det2 = det[:, :, 0].contiguous()
+    for _ in range(3):
+        D.detect_onsets_offsets_batch(det2, 0.5, 0.48, True)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    n_fmt = 20
+    for _ in range(n_fmt):
+        D.detect_onsets_offsets_batch(det2, 0.5, 0.48, True)
+    host_fmt_ms = (time.perf_counter() - t1) / n_fmt * 1e3
+
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tpath):
@@ -168,9 +202,15 @@ def main():
         "config": {"workload": "HTS-AT front-end 32 kHz n_fft=1024 hop=320 64 mel, 256 x 10 s clips per GPU "
                                "(BASELINE.json configs[1]) + detector decode of the same streams",
                    "clips_per_gpu": B_PER_GPU, "device_prewarm_s": PREWARM_S, "samples_per_clip": L, "frames_per_clip": T, "pcm": "f32",
-                   "parallelism": f"streams sharded over {world} GPU(s), all-gather of event buffers"},
+                   "parallelism": f"streams sharded over {world} GPU(s), all-gather of event record buffers",
+                   "step_covers": "fused log-mel kernel + threshold/merge kernel + record kernel (+ all-gather for N > 1), "
+                                  "all on the device; formatting events as host dictionaries is outside the step",
+                   "decode_with_host_formatting_ms": host_fmt_ms,
+                   "decode_with_host_formatting_note": "detect_onsets_offsets_batch on the same 256 streams: kernel + "
+                                                       "device-to-host copy + Python formatting, per call"},
         "roofline": {"bound": "hbm", "kernel": "stft_mel_kernel<n_fft=1024, power, mel+log>", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "traffic_source": "profiles/hbm_traffic.json (rocprofv3 PMC passes of this command, not this run)",
                      "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms,
                      "kernel_ms_p10_p50_p90": [pct(0.1), pct(0.5), pct(0.9)]},
     }

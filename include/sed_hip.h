@@ -119,6 +119,11 @@ int sed_plan_get_mel_weights(const sed_plan* plan, float* melW_host /* [n_fft/2+
 int sed_plan_get_window(const sed_plan* plan, float* window_host /* [n_fft] */);
 /* Replace the mel matrix (e.g. the one found in a loaded checkpoint).  Host pointer. */
 int sed_plan_set_mel_weights(sed_plan* plan, const float* melW_host /* [n_fft/2+1][n_mels] */);
+/* Replace the analysis window by the caller's fp32 values (all n_fft of them, zero padding included).  The plan's own
+ * window is the closed form evaluated in fp64 and rounded once; torchaudio.compliance.kaldi builds its 'hanning' window
+ * with torch.hann_window(win_length, periodic=False) in fp32 (external/audio_mamba/src/dataloader.py:133), whose bits
+ * differ from that in the last place, and this call installs exactly those.  Host pointer. */
+int sed_plan_set_window(sed_plan* plan, const float* window_host /* [n_fft] */);
 /* Per-mel affine epilogue out = x*scale[m] + shift[m]: eval-mode bn0 (htsat.py:463,767-769) or the
  * CRNN StandardScaler (src/models/crnn/process_audio.py:271-279).  Host pointers; NULL,NULL disables. */
 int sed_plan_set_affine(sed_plan* plan, const float* scale_host, const float* shift_host);
@@ -205,6 +210,18 @@ int sed_threshold_merge_runs(const float* probs, int64_t B, int64_t T, int64_t C
                              const double* time_table, int32_t table_len, double gap, int32_t* packed, int32_t cap,
                              void* stream);
 
+/* Event records of a stream batch for the exchange between GPUs (the per-file event lists the reference builds in
+ * src/models/yamnet_train.py:274-283 and src/models/crnn/utils.py:99-134, as frame indices): for every stream, its
+ * runs of all classes in class-major, onset-ascending order as int32 records (stream + first_stream, class, first
+ * frame, end frame).  records int32 [n_streams][cap_out + 1][4]: row 0 of a stream = (records kept, records dropped
+ * because they did not fit cap_out, 0, 0), rows 1.. = the records, unused rows zero.  The runs of trace
+ * (s, c) start at runs + (s*C + c)*runs_stride ints (pairs, at most cap_in of them), its count is
+ * counts[(s*C + c)*counts_stride]: (2*cap, 1) for the buffers of sed_threshold_runs / sed_merge_runs, and
+ * runs = packed + 1, counts = packed, both strides 1 + 2*cap for the buffer of sed_threshold_merge_runs. */
+int sed_pack_events(const int32_t* runs, int64_t runs_stride, const int32_t* counts, int64_t counts_stride,
+                    int64_t n_streams, int64_t C, int32_t cap_in, int32_t first_stream, int32_t* records,
+                    int32_t cap_out, void* stream);
+
 /* ---- detector -> classifier hand-off ----------------------------------------------------------------- */
 
 /* Cuts event e = samples [start, end) of stream ev_stream[e] out of the resident PCM batch into row e of a
@@ -249,7 +266,7 @@ int sed_framewise_expand(const float* x, int64_t B, int64_t T, int64_t C, int32_
  * (librosa.load(file_path, sr=16000), src/models/yamnet_train.py:46 and src/models/single_stage_yamnet_frame.py:25-27;
  * librosa.resample(track, ofs, rfs), external/hts_audio_transformer/utils.py:211), i.e. soxr_hq, whose filter lives in
  * libsoxr: this entry point replaces those calls only when they are given res_type='polyphase'.
- * Supported: target_sr/g <= 1024 and at most 128 filter coefficients per phase (orig_sr/target_sr up to about 6),
+ * Supported: target_sr/g <= 512 and at most 128 filter coefficients per phase (orig_sr/target_sr up to about 6),
  * else SED_ERR_BAD_ARG. */
 typedef struct sed_resampler sed_resampler;
 int sed_resampler_create(int32_t orig_sr, int32_t target_sr, sed_resampler** out);

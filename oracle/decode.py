@@ -99,11 +99,13 @@ def contiguous_regions(activity):
     """src/models/crnn/utils.py:77-89: (start, end_exclusive) of runs of ones, zero-padded both sides."""
     a = np.concatenate([[0], np.asarray(activity), [0]])
     d = a[1:] - a[:-1]
-    return list(zip(np.flatnonzero(d == 1).tolist(), np.flatnonzero(d == -1).tolist()))
+    return list(zip(np.flatnonzero(d == 1), np.flatnonzero(d == -1)))   # np.int64 indices, as the reference's np.where
 
 
 def decode_predictions(preds, filenames, class_labels, frames_per_sec):
-    """src/models/crnn/utils.py:91-134: class-major, onset-ascending; times round(k * (1/fps), 3)."""
+    """src/models/crnn/utils.py:91-134: class-major, onset-ascending; times round(k * (1/fps), 3) with k an np.int64,
+    so the product is an np.float64 and round() is numpy's rint(x * 1000) / 1000 (it differs from Python's
+    exact-decimal rounding of a Python float for some frames, e.g. frame 57 at 2000 frames/s)."""
     out = {}
     res = 1.0 / frames_per_sec
     for i in range(min(len(preds), len(filenames))):
@@ -222,3 +224,22 @@ def htsat_clip_label(pred_map):
     lab = np.argmax(pm, axis=1)
     counts = np.bincount(lab, minlength=pm.shape[1])
     return int(np.argmax(counts))
+
+
+def pack_events(runs, counts, cap, first_stream=0):
+    """Event records of a stream batch as the GPUs exchange them: runs (S, C, cap_in, 2) int, counts (S, C) ->
+    int32 (S, cap + 1, 4).  Row 0 of a stream = (records kept, records dropped, 0, 0); rows 1.. = (stream +
+    first_stream, class, onset frame, offset frame) in class-major, onset-ascending order, the order in which
+    decode_predictions (src/models/crnn/utils.py:99-134) walks a file's classes and regions; unused rows are zero."""
+    runs = np.asarray(runs)
+    counts = np.asarray(counts)
+    S, C, cap_in, _ = runs.shape
+    out = np.zeros((S, cap + 1, 4), np.int32)
+    for s in range(S):
+        recs = [(s + first_stream, c, int(runs[s, c, k, 0]), int(runs[s, c, k, 1]))
+                for c in range(C) for k in range(min(max(int(counts[s, c]), 0), cap_in))]
+        out[s, 0, 0] = min(len(recs), cap)
+        out[s, 0, 1] = max(0, len(recs) - cap)
+        for i, r in enumerate(recs[:cap]):
+            out[s, 1 + i] = r
+    return out

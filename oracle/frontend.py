@@ -40,9 +40,10 @@ import numpy as np
 
 
 def hann_periodic(win_length: int) -> np.ndarray:
-    """scipy.signal.get_window('hann', N, fftbins=True) in fp64."""
-    n = np.arange(win_length, dtype=np.float64)
-    return 0.5 - 0.5 * np.cos(2.0 * np.pi * n / win_length)
+    """The window torchlibrosa and librosa build: scipy.signal.get_window('hann', N, fftbins=True), fp64 (the call
+    itself, so that the table is the reference's bit for bit; it is 0.5 - 0.5 cos(2 pi n / N) up to a few fp64 ulp)."""
+    from scipy.signal import get_window
+    return get_window("hann", int(win_length), fftbins=True).astype(np.float64)
 
 
 def pad_center(w: np.ndarray, size: int) -> np.ndarray:
@@ -357,8 +358,12 @@ def kaldi_fbank(x, sample_frequency=16000.0, num_mel_bins=128, frame_length=25.0
     if preemphasis_coefficient != 0.0:
         prev = np.concatenate([fr[..., :1], fr[..., :-1]], axis=-1)         # replicate padding on the left
         fr = fr - dt(preemphasis_coefficient) * prev
-    n = np.arange(win, dtype=np.float64)
-    window = (0.5 - 0.5 * np.cos(2.0 * np.pi * n / (win - 1))).astype(dt)   # torch.hann_window(win, periodic=False)
+    if mode == "gold":
+        n = np.arange(win, dtype=np.float64)
+        window = 0.5 - 0.5 * np.cos(2.0 * np.pi * n / (win - 1))
+    else:  # the fp32 window torchaudio itself builds
+        import torch
+        window = torch.hann_window(win, periodic=False, dtype=torch.float32).numpy()
     fr = fr * window
     fr = np.pad(fr, ((0, 0), (0, 0), (0, n_fft - win)))
     spec = np.fft.rfft(fr, axis=-1)          # numpy >= 2 transforms fp32 input in fp32, as torch.fft.rfft does

@@ -33,6 +33,13 @@
 #define SED_SCHED_FENCE() ((void)0)
 #endif
 
+// Compile-time ablations for timing experiments (results are then garbage): -DSED_X_MASK=<bits>.
+#if defined(SED_X_MASK)
+#define SED_SKIP(bit) (((SED_X_MASK) & (bit)) != 0)
+#else
+#define SED_SKIP(bit) false
+#endif
+
 namespace sed {
 
 struct alignas(8) cplx {
@@ -121,6 +128,7 @@ SED_HD void butterfly(v2& a, v2& b) {
 template <int N>
 SED_HD void fft_dit(v2 (&x)[N]) {
   constexpr int LOG = ilog2(N);
+  if (SED_SKIP(N == 32 ? 256 : 512)) return;
   static_for<0, LOG>([&](auto S) {
     constexpr int h = 1 << decltype(S)::value;  // half span of this stage
     static_for<0, N / 2>([&](auto Bf) {
@@ -224,7 +232,7 @@ SED_HD void lane_stage1(LaneState<G>& st, const Src src, const float* win, const
     v4 w[4][Q / 2], ta[H / 2], tb[H / 2];
     auto issue_window = [&](auto Qf) {
       constexpr int q = decltype(Qf)::value;
-      static_for<0, Q / 2>([&](auto Pf) { w[q][decltype(Pf)::value] = ld4(wrow + 2 * Q * q + 4 * decltype(Pf)::value); });
+      static_for<0, Q / 2>([&](auto Pf) { w[q][decltype(Pf)::value] = SED_SKIP(2) ? v4{0.5f, 0.25f, 0.125f, (float)l} : ld4(wrow + 2 * Q * q + 4 * decltype(Pf)::value); });
     };
     auto apply_window = [&](auto Qf) {
       constexpr int q = decltype(Qf)::value;
@@ -236,7 +244,7 @@ SED_HD void lane_stage1(LaneState<G>& st, const Src src, const float* win, const
     };
     static_for<0, G::R1>([&](auto N1) {
       constexpr int n1 = decltype(N1)::value;
-      st.y[0][bitrev(n1, LOG1)] = src.load2(2 * G::R2 * n1 + 2 * l);
+      st.y[0][bitrev(n1, LOG1)] = SED_SKIP(4) ? v2{(float)(l + n1), 1.0f} : src.load2(2 * G::R2 * n1 + 2 * l);
     });
     issue_window(std::integral_constant<int, 0>{});
     issue_window(std::integral_constant<int, 1>{});
@@ -248,13 +256,13 @@ SED_HD void lane_stage1(LaneState<G>& st, const Src src, const float* win, const
     issue_window(std::integral_constant<int, 3>{});
     SED_SCHED_FENCE();
     apply_window(std::integral_constant<int, 2>{});
-    static_for<0, H / 2>([&](auto Pf) { ta[decltype(Pf)::value] = ld4(trow + 4 * decltype(Pf)::value); });
+    static_for<0, H / 2>([&](auto Pf) { ta[decltype(Pf)::value] = SED_SKIP(2) ? v4{0.5f, 0.25f, 0.125f, (float)l} : ld4(trow + 4 * decltype(Pf)::value); });
     SED_SCHED_FENCE();
     apply_window(std::integral_constant<int, 3>{});
     SED_SCHED_FENCE();
     fft_dit<G::R1>(st.y[0]);
     SED_SCHED_FENCE();
-    static_for<0, H / 2>([&](auto Pf) { tb[decltype(Pf)::value] = ld4(trow + 2 * H + 4 * decltype(Pf)::value); });
+    static_for<0, H / 2>([&](auto Pf) { tb[decltype(Pf)::value] = SED_SKIP(2) ? v4{0.5f, 0.25f, 0.125f, (float)l} : ld4(trow + 2 * H + 4 * decltype(Pf)::value); });
     static_for<0, H / 2>([&](auto Pf) {
       constexpr int i = decltype(Pf)::value;
       if constexpr (i > 0) st.y[0][2 * i] = cmul(st.y[0][2 * i], ta[i].xy);  // k1 = 0: W^0
@@ -348,16 +356,34 @@ SED_HD void lane_stage1_conditioned(LaneState<G>& st, const float* frame, const 
 }
 
 // Exchange phase PH (0: k1 in [0, R1/2), 1: k1 in [R1/2, R1)): lane l writes row n2 of the frame's region.
+// On the device the accesses are written as 8-byte LDS instructions by hand: measured on gfx950 per instruction and
+// CU, ds_read_b64 0.95 ns against 3.4 ns for the ds_read2_b64 the compiler would fuse two of them into, and
+// ds_write_b64 2.6 ns against 5.8 ns for a ds_write_b128.  The compiler does not count hand-written LDS reads, so
+// lane_xwait() must come between the last read and the first use of st.p / st.q.
+#if defined(__HIP_DEVICE_COMPILE__)
+SED_HD unsigned lds_addr(const float* p) { return (unsigned)(size_t)p; }  // low half of a generic LDS address = LDS offset
+#endif
+
 template <class G, int PH>
 SED_HD void lane_xwrite(const LaneState<G>& st, float* xfr, int l) {
   static_for<0, G::A>([&](auto Af) {
     constexpr int a = decltype(Af)::value;
     float* row = xfr + (G::A * l + a) * G::RP;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned ra = lds_addr(row);
+    static_for<0, G::R1 / 2>([&](auto Q) {
+      constexpr int q = decltype(Q)::value;
+      const unsigned addr = ra;  // (asm operands must be locals of the innermost lambda)
+      const v2 val = st.y[a][PH * (G::R1 / 2) + q];
+      asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(val), "n"(8 * q) : "memory");
+    });
+#else
     static_for<0, G::R1 / 4>([&](auto Q) {
       constexpr int q = decltype(Q)::value;
       constexpr int k1 = PH * (G::R1 / 2) + 2 * q;
       st4(row + 4 * q, __builtin_shufflevector(st.y[a][k1], st.y[a][k1 + 1], 0, 1, 2, 3));
     });
+#endif
   });
 }
 
@@ -372,12 +398,39 @@ template <class G, int PH>
 SED_HD void lane_xread(LaneState<G>& st, const float* xfr, int l) {
   constexpr int LOG2 = ilog2(G::R2);
   const float* col = xfr + 2 * lane_xcol<G, PH>(l);
+#if defined(__HIP_DEVICE_COMPILE__)
+  const unsigned ca = lds_addr(col);
+#endif
   static_for<0, G::R2>([&](auto N2) {
     constexpr int n2 = decltype(N2)::value;
     constexpr int pos = bitrev(n2, LOG2);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned addr = ca;
+    v2 val;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(val) : "v"(addr), "n"(4 * n2 * G::RP) : "memory");
+    if constexpr (PH == 0) st.p[pos] = val;
+    else st.q[pos] = val;
+#else
     if constexpr (PH == 0) st.p[pos] = ld2(col + n2 * G::RP);
     else st.q[pos] = ld2(col + n2 * G::RP);
+#endif
   });
+}
+
+// Completion of the hand-written exchange reads: every value is tied to the wait, so no use can move above it.
+template <class G>
+SED_HD void lane_xwait(LaneState<G>& st) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  static_assert(G::R2 == 16 || G::R2 == 32, "operand lists below");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  static_for<0, G::R2>([&](auto Bf) {
+    constexpr int b = decltype(Bf)::value;
+    v2 x = st.p[b], y = st.q[b];
+    asm volatile("" : "+v"(x), "+v"(y));
+    st.p[b] = x;
+    st.q[b] = y;
+  });
+#endif
 }
 
 // Split slots.  After stage 2 a lane l > 0 holds P[s] = Z[l + R1 s] and Q[s] = Z[(R1 - l) + R1 s]; bin k = l + R1 s
@@ -398,8 +451,17 @@ SED_HD int lane_slot_bin(int l, int t) {
 // With E = U + conj V, O = -i (U - conj V), T = W O:  X[k] = E + T,  conj X[NC-k] = E - T.
 template <class G, bool MAGNITUDE>
 SED_HD void lane_stage2_power(LaneState<G>& st, float* pw, const float* tw2, int l) {
+  // the split twiddles of all slots are in flight while the transforms run
+  const float* srow = tw2 + l * G::SROW;
+  v4 wtab[(G::SLOTS + 1) / 2];
+  static_for<0, (G::SLOTS + 1) / 2>([&](auto Tf) {
+    constexpr int t2 = decltype(Tf)::value;
+    wtab[t2] = SED_SKIP(2) ? v4{0.5f, 0.25f, 0.125f, (float)l} : ld4(srow + 4 * t2);
+  });
+  SED_SCHED_FENCE();
   fft_dit<G::R2>(st.p);
   fft_dit<G::R2>(st.q);
+  SED_SCHED_FENCE();
   const bool l0 = (l == 0);
   const int off = l0 ? G::R1 / 2 : 0;
   float* lo_p = pw + l;                 // pw[k] of P slots at lo_p[R1 s]
@@ -407,11 +469,9 @@ SED_HD void lane_stage2_power(LaneState<G>& st, float* pw, const float* tw2, int
   float* hi_p = pw + G::R1 - l;         // pw[NC - k] of P slots at hi_p[R1 (R2-1-s)]
   float* hi_q = hi_p - off;
   const v2 k = v2{1.0f, -1.0f};
-  const float* srow = tw2 + l * G::SROW;
-  v4 wpair = v4{0.0f, 0.0f, 0.0f, 0.0f};
   static_for<0, G::SLOTS>([&](auto Tf) {
     constexpr int t = decltype(Tf)::value;
-    if constexpr (t % 2 == 0) wpair = ld4(srow + 2 * t);  // twiddles of slots t and t + 1
+    const v4 wpair = wtab[t / 2];  // twiddles of slots t and t + 1
     constexpr bool qslot = t > G::R2 / 2;
     constexpr int s = qslot ? t - 1 : t;
     v2 u, v;
@@ -431,7 +491,7 @@ SED_HD void lane_stage2_power(LaneState<G>& st, float* pw, const float* tw2, int
     if constexpr (MAGNITUDE) pp = v2{__builtin_sqrtf(pp.x), __builtin_sqrtf(pp.y)};
     float* lo = qslot ? lo_q : lo_p;
     float* hi = qslot ? hi_q : hi_p;
-    if (t != G::R2 / 2 + 1 || l0) {
+    if ((t != G::R2 / 2 + 1 || l0) && !(SED_SKIP(16) && pp.x != 12345.0f)) {
       lo[G::R1 * s] = pp.x;
       hi[G::R1 * (G::R2 - 1 - s)] = pp.y;
     }

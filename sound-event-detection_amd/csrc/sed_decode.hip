@@ -302,6 +302,30 @@ __global__ void __launch_bounds__(256) threshold_merge_kernel(const float* probs
   if (lane == 0) rec[0] = n_out;
 }
 
+// Event records of one stream for the exchange between GPUs: all classes' runs of a stream, class-major and
+// onset-ascending (the order decode_predictions emits), as (stream, class, first frame, end frame) records behind a
+// header row (records kept, records dropped, 0, 0).  One wavefront per stream; the class offsets are a running sum over
+// the (few) classes, the copies are 64 events wide.  Every row of the output is written, so the buffer needs no clearing.
+__global__ void __launch_bounds__(256) pack_events_kernel(const int32_t* runs, int64_t runs_stride, const int32_t* counts,
+                                                          int64_t counts_stride, int64_t n_streams, int C, int cap_in,
+                                                          int first_stream, int32_t* records, int cap_out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (s >= n_streams) return;
+  int4* rec = reinterpret_cast<int4*>(records) + s * (int64_t)(cap_out + 1);
+  int base = 0;
+  for (int c = 0; c < C; ++c) {
+    const int64_t trace = s * C + c;
+    const int n = min(max(counts[trace * counts_stride], 0), cap_in);
+    const int32_t* r = runs + trace * runs_stride;
+    for (int k = lane; k < n && base + k < cap_out; k += 64)
+      rec[1 + base + k] = make_int4((int)s + first_stream, c, r[2 * k], r[2 * k + 1]);
+    base += n;
+  }
+  const int kept = min(base, cap_out);
+  for (int k = kept + lane; k < cap_out; k += 64) rec[1 + k] = make_int4(0, 0, 0, 0);
+  if (lane == 0) rec[0] = make_int4(kept, base - kept, 0, 0);
+}
 
 }  // namespace sed
 
@@ -388,6 +412,18 @@ extern "C" int sed_threshold_merge_runs(const float* probs, int64_t B, int64_t T
   if (!packed || !time_table || (T > 0 && !probs)) return SED_ERR_BAD_ARG;
   hipLaunchKernelGGL(threshold_merge_kernel, dim3(blocks_for(B * C)), dim3(256), 0, (hipStream_t)stream, probs, B * C,
                      (int)T, (int)C, threshold, (int)smoothing, time_table, (int)table_len, gap, packed, (int)cap);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int sed_pack_events(const int32_t* runs, int64_t runs_stride, const int32_t* counts, int64_t counts_stride,
+                               int64_t n_streams, int64_t C, int32_t cap_in, int32_t first_stream, int32_t* records,
+                               int32_t cap_out, void* stream) {
+  if (n_streams < 0 || C < 0 || cap_in < 0 || cap_out < 1 || runs_stride < 0 || counts_stride < 0) return SED_ERR_BAD_ARG;
+  if (C > INT32_MAX || n_streams + (int64_t)first_stream > INT32_MAX) return SED_ERR_BAD_ARG;
+  if (n_streams == 0) return SED_OK;
+  if (!records || (C > 0 && (!runs || !counts))) return SED_ERR_BAD_ARG;
+  hipLaunchKernelGGL(pack_events_kernel, dim3(blocks_for(n_streams)), dim3(256), 0, (hipStream_t)stream, runs, runs_stride,
+                     counts, counts_stride, n_streams, (int)C, (int)cap_in, (int)first_stream, records, (int)cap_out);
   return hip_status(hipGetLastError());
 }
 

@@ -31,7 +31,7 @@ using Geo512 = Geo<16, 16, 8, 12>;
 using Geo1024 = Geo<32, 16, 16, 12>;
 using Geo2048 = Geo<32, 32, 16, 4>;
 
-#if defined(SED_TIMELINE) || defined(SED_X_MASK)
+#if defined(SED_TIMELINE) || defined(SED_X_MASK) || defined(SED_STAMPS)
 #define SED_DIAGNOSTIC_BUILD 1  // diagnostic builds read SED_DEBUG_WAVES from the environment
 #endif
 
@@ -39,13 +39,6 @@ constexpr int kMaxMelSets = 4;
 constexpr int kMelBurst = 8;    // steps of 4 bins whose MFMA operands are fetched from LDS in one burst
 constexpr int kPartStride = 20;  // floats between the partial sums of consecutive positions: [frame][filter] + pad (4*odd: bank spread)
 constexpr int kMaxSpanBlocks = 32;  // 1 KB blocks of a staged span: (FPW - 1) * hop + n_fft <= 4 * 2048 samples
-
-// Compile-time ablations for timing experiments (results are then garbage): -DSED_X_MASK=<bits>.
-#if defined(SED_X_MASK)
-#define SED_SKIP(bit) (((SED_X_MASK) & (bit)) != 0)
-#else
-#define SED_SKIP(bit) false
-#endif
 
 // The tables of a plan as one image in global memory, laid out exactly as the kernel keeps them in LDS (so the
 // prologue is a straight 16-byte copy): [window | inter-stage twiddles | split twiddles] (lane-major, see Geo), then
@@ -75,6 +68,22 @@ struct FrontParams {
   int32_t mel_sets, mel_u, mel_maxpos, n_quads, out_vec;
   unsigned long long* stamps;  // SED_TIMELINE builds only
 };
+
+// In-kernel phase timing (diagnostic build, -DSED_STAMPS): cycles per phase summed per wavefront.
+#ifdef SED_STAMPS
+#define SED_STAMP_DECL unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_t = sed_stamp();
+#define SED_STAMP(k) { const unsigned long long t_ = sed_stamp(); st_acc[k] += t_ - st_t; st_t = t_; }
+__device__ __forceinline__ unsigned long long sed_stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#else
+#define SED_STAMP_DECL
+#define SED_STAMP(k)
+#endif
 
 // Orders LDS accesses of different lanes of ONE wavefront.  The hardware executes a wavefront's LDS operations in
 // the order they were issued, so no wait is needed: this only stops the compiler from moving memory operations
@@ -194,21 +203,43 @@ __device__ __forceinline__ void stage_span_dma(const FrontParams& p, float* dst,
   });
 }
 
+// Shape of a plan's mel schedule.  The shapes of the reference's own flavours are compiled in, which turns the
+// loops over accumulator sets, steps and positions into straight-line code; any other filterbank runs the same code with
+// the shape read from the launch parameters.
+template <int SETS_, int U_, int MAXPOS_, int ROUNDS_>
+struct MelStatic {
+  static constexpr bool kStatic = true;
+  static constexpr int SETS = SETS_, U = U_, MAXPOS = MAXPOS_, ROUNDS = ROUNDS_;
+};
+struct MelDynamic {
+  static constexpr bool kStatic = false;
+  static constexpr int SETS = 0, U = 0, MAXPOS = 0, ROUNDS = 0;
+};
+template <class Mel> __device__ __forceinline__ int mel_sets_of(const FrontParams& p) { if constexpr (Mel::kStatic) return Mel::SETS; else return p.mel_sets; }
+template <class Mel> __device__ __forceinline__ int mel_u_of(const FrontParams& p) { if constexpr (Mel::kStatic) return Mel::U; else return p.mel_u; }
+template <class Mel> __device__ __forceinline__ int mel_maxpos_of(const FrontParams& p) { if constexpr (Mel::kStatic) return Mel::MAXPOS; else return p.mel_maxpos; }
+template <class Mel> __device__ __forceinline__ bool mel_two_rounds(const FrontParams& p) { if constexpr (Mel::kStatic) return Mel::ROUNDS > 1; else return p.n_quads > 16; }
+
 // Mel projection of 4 frames (power rows prow0 + j*PITCH, j = 0..3) on the matrix pipe.
 // Lane 4*block + j feeds the power of frame j as the B operand and the weight of filter 4*quad + j as the
 // A operand of block `block`; after the last instruction it holds, in acc[i], the partial sum of filter
 // 4*quad + i for frame j over the bins of position (set, block).  The weight table carries one all-zero step per
 // set, so an odd step count needs no special case.  The partial sums go to LDS, kPartStride floats per position.
+template <class Mel>
 __device__ __forceinline__ void mel_mfma_4frames(const FrontParams& p, const int32_t* boffL, const float* prow0,
                                                  const float* mela, float* part, int lane) {
   asm volatile("" : "+v"(lane));  // keeps the per-lane table reads inside the streaming loop instead of pinning registers
   const int blk = lane >> 2, j = lane & 3;
-  const int U = p.mel_u;
+  const int U = mel_u_of<Mel>(p);
+  const int sets = SED_SKIP(32) ? 0 : mel_sets_of<Mel>(p);
   int boff[kMaxMelSets];
-  static_for<0, kMaxMelSets>([&](auto Sf) { boff[decltype(Sf)::value] = boffL[decltype(Sf)::value * 64 + lane]; });
   static_for<0, kMaxMelSets>([&](auto Sf) {
     constexpr int s = decltype(Sf)::value;
-    if (s < (SED_SKIP(32) ? 0 : p.mel_sets)) {
+    boff[s] = (!Mel::kStatic || s < Mel::SETS) ? boffL[s * 64 + lane] : 0;
+  });
+  static_for<0, kMaxMelSets>([&](auto Sf) {
+    constexpr int s = decltype(Sf)::value;
+    if (s < sets) {
       const float* bp = prow0 + boff[s];
       const float* ap = mela + ((size_t)s * (U + 1) * 64 + lane) * 4;
       v4 acc = v4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -250,6 +281,7 @@ __device__ __forceinline__ void mel_mfma_4frames(const FrontParams& p, const int
 // the optional affine.  It then holds 4 consecutive filters of one frame.  The gather word of a lane holds the float
 // offset of its quad's first partial sum (bits 0-15) and the quad's number of positions (bits 16-20); lanes whose quad
 // has fewer positions than the widest one read a block of zeros instead.
+template <class Mel>
 __device__ __forceinline__ v4 mel_gather_log(const FrontParams& p, const int32_t* gwL, const float* affL,
                                              const float* zero4, const float* part, int r, int lane) {
   asm volatile("" : "+v"(lane));
@@ -257,7 +289,9 @@ __device__ __forceinline__ v4 mel_gather_log(const FrontParams& p, const int32_t
   const int npos = g >> 16;
   const float* first = part + (g & 0xffff);
   v4 sum = ld4(first);  // every quad has at least one position
-  for (int i0 = 1; i0 < p.mel_maxpos; i0 += 2) {  // wave-uniform trip count
+  const int maxpos = mel_maxpos_of<Mel>(p);
+#pragma unroll
+  for (int i0 = 1; i0 < maxpos; i0 += 2) {  // wave-uniform trip count
     const v4 x = ld4(i0 < npos ? first + i0 * kPartStride : zero4);
     const v4 y = ld4(i0 + 1 < npos ? first + (i0 + 1) * kPartStride : zero4);
     sum += x + y;
@@ -307,7 +341,7 @@ __device__ __forceinline__ void mel_store(const FrontParams& p, float* dst, v4 v
 // apart (measured: the first after 58 % of the kernel time) and the last ones run on a nearly empty CU; with the
 // queue they all stay busy until the range is drained.  The span of the next group is ordered as soon as the current
 // one's power rows are consumed, whichever clip it belongs to.
-template <class G, bool MAG, bool SPEC_OUT, bool PRE, bool I16>
+template <class G, bool MAG, bool SPEC_OUT, bool PRE, bool I16, class Mel>
 __global__ void __launch_bounds__(G::WAVES * 64) __attribute__((amdgpu_waves_per_eu(G::WAVES / 4, G::WAVES / 4)))
 stft_mel_kernel(const FrontParams p) {
   extern __shared__ __align__(16) float smem[];
@@ -354,6 +388,7 @@ stft_mel_kernel(const FrontParams p) {
     v4 hval[kGroups][2];
     float* hdst = nullptr;
     int hvalid = 0;
+    SED_STAMP_DECL
     while (true) {
       // take the next group now; the answer is needed when its span is ordered, half an iteration from here
       int taken = 0;
@@ -367,14 +402,16 @@ stft_mel_kernel(const FrontParams p) {
           stage_span<I16>(p, X, b, s0, p.span, lane);
         }
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      SED_STAMP(0)
+      if (!SED_SKIP(1024)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       wave_phase_fence();
+      SED_STAMP(1)
       if constexpr (!SPEC_OUT) {
         if (held) {
           static_for<0, kGroups>([&](auto Gf) {
             constexpr int g = decltype(Gf)::value;
             mel_store(p, hdst + 4 * g * p.n_mels, hval[g][0], 0, hvalid - 4 * g, lane);
-            if (p.n_quads > 16) mel_store(p, hdst + 4 * g * p.n_mels, hval[g][1], 1, hvalid - 4 * g, lane);
+            if (mel_two_rounds<Mel>(p)) mel_store(p, hdst + 4 * g * p.n_mels, hval[g][1], 1, hvalid - 4 * g, lane);
           });
         }
       }
@@ -394,6 +431,7 @@ stft_mel_kernel(const FrontParams p) {
         lane_stage1<G>(st, SrcF32{X + fi * p.hop}, winL, tw1L, l);
       }
       wave_phase_fence();
+      SED_STAMP(2)
       float* xfr = X + fi * G::XFR;
       if (!SED_SKIP(8)) {
         lane_xwrite<G, 0>(st, xfr, l);
@@ -403,14 +441,17 @@ stft_mel_kernel(const FrontParams p) {
         lane_xwrite<G, 1>(st, xfr, l);
         wave_phase_fence();
         lane_xread<G, 1>(st, xfr, l);
+        lane_xwait<G>(st);
         wave_phase_fence();
       } else {
         static_for<0, G::R2>([&](auto Nf) { st.p[decltype(Nf)::value] = st.y[0][decltype(Nf)::value]; st.q[decltype(Nf)::value] = st.y[0][G::R1 - 1 - decltype(Nf)::value]; });
       }
+      SED_STAMP(3)
       float* pw = X + fi * G::PP;
       lane_stage2_power<G, MAG>(st, pw, tw2L, l);
       for (int k = G::NBINS + l; k < G::PP; k += G::LPF) pw[k] = 0.0f;  // row padding read (with zero weight) by the mel stage
       wave_phase_fence();
+      SED_STAMP(4)
       const int nvalid = min(G::FPW, p.T - f0);
       // the group after this one: the one just taken from the queue
       gi = g_begin + __builtin_amdgcn_readfirstlane(taken);
@@ -426,7 +467,8 @@ stft_mel_kernel(const FrontParams p) {
         float* part = X + p.part_off;
         static_for<0, kGroups>([&](auto Gf) {
           constexpr int g = decltype(Gf)::value;
-          mel_mfma_4frames(p, boffL, X + 4 * g * G::PP, melaL, part, lane);
+          mel_mfma_4frames<Mel>(p, boffL, X + 4 * g * G::PP, melaL, part, lane);
+          SED_STAMP(5)
           if constexpr (g == kGroups - 1) {
             // the power rows are consumed: the next group's span may land on them while the gather runs
             const int64_t s1 = (int64_t)nf0 * p.hop - p.pad_left;
@@ -436,8 +478,8 @@ stft_mel_kernel(const FrontParams p) {
             }
           }
           if (!SED_SKIP(64)) {
-            hval[g][0] = mel_gather_log(p, gwL, affL, zeroL, part, 0, lane);
-            if (p.n_quads > 16) hval[g][1] = mel_gather_log(p, gwL, affL, zeroL, part, 1, lane);
+            hval[g][0] = mel_gather_log<Mel>(p, gwL, affL, zeroL, part, 0, lane);
+            if (mel_two_rounds<Mel>(p)) hval[g][1] = mel_gather_log<Mel>(p, gwL, affL, zeroL, part, 1, lane);
           }
           wave_phase_fence();
         });
@@ -446,6 +488,7 @@ stft_mel_kernel(const FrontParams p) {
         hvalid = nvalid;
       }
       wave_phase_fence();
+      SED_STAMP(6)
       if (!more) break;
       b = nb;
       f0 = nf0;
@@ -455,10 +498,14 @@ stft_mel_kernel(const FrontParams p) {
         static_for<0, kGroups>([&](auto Gf) {
           constexpr int g = decltype(Gf)::value;
           mel_store(p, hdst + 4 * g * p.n_mels, hval[g][0], 0, hvalid - 4 * g, lane);
-          if (p.n_quads > 16) mel_store(p, hdst + 4 * g * p.n_mels, hval[g][1], 1, hvalid - 4 * g, lane);
+          if (mel_two_rounds<Mel>(p)) mel_store(p, hdst + 4 * g * p.n_mels, hval[g][1], 1, hvalid - 4 * g, lane);
         });
       }
     }
+#ifdef SED_STAMPS
+    if (lane == 0 && p.stamps)
+      for (int k = 0; k < 8; ++k) p.stamps[(size_t)(blockIdx.x * wg_waves + wave) * 8 + k] = st_acc[k];
+#endif
   }
 #ifdef SED_TIMELINE
   if (lane == 0 && p.stamps) {
@@ -810,6 +857,17 @@ extern "C" int sed_plan_set_mel_weights(sed_plan* pl, const float* melW) {
   return upload_tables(pl);
 }
 
+extern "C" int sed_plan_set_window(sed_plan* pl, const float* window) {
+  if (!pl || !window) return SED_ERR_BAD_ARG;
+  for (int i = 0; i < pl->cfg.n_fft; ++i)
+    if (!std::isfinite(window[i])) return SED_ERR_BAD_ARG;
+  int rc = check_device(pl);
+  if (rc) return rc;
+  SED_HIP_TRY(hipDeviceSynchronize());
+  for (int i = 0; i < pl->cfg.n_fft; ++i) pl->window_host[i] = (double)window[i];
+  return upload_tables(pl);
+}
+
 extern "C" int sed_plan_set_affine(sed_plan* pl, const float* scale, const float* shift) {
   if (!pl || ((scale == nullptr) != (shift == nullptr))) return SED_ERR_BAD_ARG;
   int rc = check_device(pl);
@@ -827,9 +885,8 @@ extern "C" int sed_plan_set_affine(sed_plan* pl, const float* scale, const float
   return upload_tables(pl);
 }
 
-template <class G, bool MAG, bool SPEC_OUT, bool PRE_ = false>
-static int launch_front(const sed_plan* pl, FrontParams p, int64_t B, hipStream_t stream) {
-  constexpr bool PRE = PRE_;
+template <class G, bool MAG, bool SPEC_OUT, bool PRE, class Mel>
+static int launch_front_shape(const sed_plan* pl, FrontParams p, int64_t B, hipStream_t stream) {
   // per-wave LDS region
   p.span = round4((G::FPW - 1) * p.hop + G::NFFT);
   p.span_blocks = (p.span + 255) / 256;
@@ -856,10 +913,10 @@ static int launch_front(const sed_plan* pl, FrontParams p, int64_t B, hipStream_
   if (lds_bytes > 160 * 1024) return SED_ERR_BAD_ARG;
 #ifdef SED_ONLY_BENCH  // diagnostic builds: one instantiation only, seconds to compile
   if ((p.pcm_kind & ~kPcmDiv3) == SED_PCM_I16) return SED_ERR_BAD_ARG;
-  auto kern = stft_mel_kernel<G, MAG, SPEC_OUT, PRE, false>;
+  auto kern = stft_mel_kernel<G, MAG, SPEC_OUT, PRE, false, Mel>;
 #else
-  auto kern = (p.pcm_kind & ~kPcmDiv3) == SED_PCM_I16 ? stft_mel_kernel<G, MAG, SPEC_OUT, PRE, true>
-                                                       : stft_mel_kernel<G, MAG, SPEC_OUT, PRE, false>;
+  auto kern = (p.pcm_kind & ~kPcmDiv3) == SED_PCM_I16 ? stft_mel_kernel<G, MAG, SPEC_OUT, PRE, true, Mel>
+                                                       : stft_mel_kernel<G, MAG, SPEC_OUT, PRE, false, Mel>;
 #endif
   // the dynamic LDS limit is a property of the kernel function, set once per instantiation (per device: the attribute
   // lives in the device's code object) to the hardware maximum, so that concurrent launches with different sizes
@@ -914,10 +971,57 @@ static int launch_front(const sed_plan* pl, FrontParams p, int64_t B, hipStream_
     fprintf(stderr, "\n");
   }
   return hip_status(hipGetLastError());
+#elif defined(SED_STAMPS)
+  static unsigned long long* d_stamps = nullptr;
+  const size_t n_st = (size_t)blocks * waves * 8;
+  if (!d_stamps) { (void)hipMalloc((void**)&d_stamps, 4096 * 8 * 8 * sizeof(unsigned long long)); (void)hipMemset(d_stamps, 0, 4096 * 8 * 8 * sizeof(unsigned long long)); }
+  p.stamps = d_stamps;
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(waves * 64), lds_bytes, stream, p);
+  static int calls = 0;
+  if (++calls == 100) {
+    (void)hipDeviceSynchronize();
+    std::vector<unsigned long long> h(n_st);
+    (void)hipMemcpy(h.data(), d_stamps, n_st * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    double sum[8] = {0};
+    for (size_t w = 0; w < n_st / 8; ++w) for (int k = 0; k < 8; ++k) sum[k] += (double)h[w * 8 + k];
+    const char* names[8] = {"queue pop + span issue", "wait for the span", "stores + stage 1", "exchange", "stage 2 + power", "mel mfma", "span order + gather + log", "-"};
+    double tot = 0; for (int k = 0; k < 8; ++k) tot += sum[k];
+    for (int k = 0; k < 7; ++k) fprintf(stderr, "STAMP %-28s %10.0f ticks/wave  %5.1f%%\n", names[k], sum[k] / (n_st / 8), 100.0 * sum[k] / tot);
+    fprintf(stderr, "STAMP total %10.0f ticks/wave over %zu waves\n", tot / (n_st / 8), n_st / 8);
+  }
+  return hip_status(hipGetLastError());
 #else
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(waves * 64), lds_bytes, stream, p);
   return hip_status(hipGetLastError());
 #endif
+}
+
+// Picks the compiled-in mel shape when the plan's schedule has it (the flavour's default filterbank does).
+template <class G, bool MAG, bool SPEC_OUT, bool PRE_ = false>
+static int launch_front(const sed_plan* pl, const FrontParams& p, int64_t B, hipStream_t stream) {
+  constexpr bool PRE = PRE_;
+  if constexpr (!SPEC_OUT) {
+    const bool two = p.n_quads > 16;
+    auto is = [&](int sets, int u, int maxpos, bool rounds2) {
+      return p.mel_sets == sets && p.mel_u == u && p.mel_maxpos == maxpos && two == rounds2;
+    };
+    if constexpr (G::NFFT == 1024 && !MAG && !PRE) {  // HTS-AT: Slaney 64 mel, 50..14000 Hz at 32 kHz
+      if (is(2, 6, 5, false)) return launch_front_shape<G, MAG, SPEC_OUT, PRE, MelStatic<2, 6, 5, 1>>(pl, p, B, stream);
+    }
+    if constexpr (G::NFFT == 512 && MAG && !PRE) {  // YAMNet: HTK 64 mel, 125..7500 Hz at 16 kHz
+      if (is(2, 3, 4, false)) return launch_front_shape<G, MAG, SPEC_OUT, PRE, MelStatic<2, 3, 4, 1>>(pl, p, B, stream);
+    }
+    if constexpr (G::NFFT == 2048 && MAG && !PRE) {  // CRNN: Slaney 40 mel, 0..22050 Hz at 44.1 kHz
+      if (is(3, 7, 15, false)) return launch_front_shape<G, MAG, SPEC_OUT, PRE, MelStatic<3, 7, 15, 1>>(pl, p, B, stream);
+    }
+    if constexpr (G::NFFT == 2048 && !MAG && !PRE) {  // dB mel: Slaney 64 mel, 0..22050 Hz at 44.1 kHz
+      if (is(3, 8, 9, false)) return launch_front_shape<G, MAG, SPEC_OUT, PRE, MelStatic<3, 8, 9, 1>>(pl, p, B, stream);
+    }
+    if constexpr (G::NFFT == 512 && !MAG && PRE) {  // Kaldi fbank: 128 mel, 20..8000 Hz at 16 kHz
+      if (is(4, 2, 4, true)) return launch_front_shape<G, MAG, SPEC_OUT, PRE, MelStatic<4, 2, 4, 2>>(pl, p, B, stream);
+    }
+  }
+  return launch_front_shape<G, MAG, SPEC_OUT, PRE, MelDynamic>(pl, p, B, stream);
 }
 
 template <bool SPEC_OUT>

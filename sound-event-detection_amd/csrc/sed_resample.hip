@@ -501,8 +501,11 @@ extern "C" int sed_resampler_forward(const sed_resampler* r, const void* pcm, in
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return rs_status(e);
   if (dev != r->device) return SED_ERR_WRONG_DEVICE;
-  const bool dma = r->dma_groups > 0 && (uintptr_t)pcm % (pcm_kind == SED_PCM_F32 ? 4 : 2) == 0 &&
-                   getenv("SED_RS_NO_DMA") == nullptr && (pcm_kind == SED_PCM_F32 || getenv("SED_RS_NO_DMA16") == nullptr);
+  bool dma = r->dma_groups > 0 && (uintptr_t)pcm % (pcm_kind == SED_PCM_F32 ? 4 : 2) == 0;
+#ifdef SED_DIAGNOSTIC_BUILD  // timing experiments only: force the register-staged path
+  static const bool no_dma = getenv("SED_RS_NO_DMA") != nullptr, no_dma16 = getenv("SED_RS_NO_DMA16") != nullptr;
+  dma = dma && !no_dma && (pcm_kind == SED_PCM_F32 || !no_dma16);
+#endif
   const int threads = r->threads, R = dma ? r->dma_groups : r->groups;
   ResampleParams p;
   p.pcm = pcm;

@@ -182,8 +182,9 @@ def _format_events(results, filenames, class_labels, frames_per_sec, n_files, ge
         results[filename] = []
         for class_idx, label in class_labels.items():
             for s, e in get_pairs(i, class_idx):
-                results[filename].append({"file": filename, "event_onset": round(int(s) * time_resolution, 3),
-                                          "event_offset": round(int(e) * time_resolution, 3), "event_label": label})
+                # np.int64 * float -> np.float64, whose round() is numpy's (crnn/utils.py:122-129 does the same)
+                results[filename].append({"file": filename, "event_onset": round(np.int64(s) * time_resolution, 3),
+                                          "event_offset": round(np.int64(e) * time_resolution, 3), "event_label": label})
     return results
 
 

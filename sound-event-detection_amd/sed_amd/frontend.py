@@ -131,6 +131,11 @@ class _Plan:
         c = cfg.to_c()
         with torch.cuda.device(device):
             L.check(L.lib.sed_plan_create(C.byref(c), C.byref(self.ptr)), "sed_plan_create")
+            if cfg.window_kind == L.WINDOW_HANN_SYMMETRIC and cfg.win_align == L.WIN_LEFT:
+                # the Kaldi flavour: the very window torchaudio builds (torch.hann_window in fp32), bit for bit
+                w = torch.zeros(cfg.n_fft, dtype=torch.float32)
+                w[:cfg.win_length] = torch.hann_window(cfg.win_length, periodic=False, dtype=torch.float32)
+                L.check(L.lib.sed_plan_set_window(self.ptr, w.data_ptr()), "sed_plan_set_window")
 
     def num_frames(self, n_samples: int) -> int:
         t = int(L.lib.sed_plan_num_frames(self.ptr, int(n_samples)))
@@ -344,20 +349,38 @@ class LogMelFrontend(_PlanHolder):
     kernel's epilogue.
     """
 
-    def __init__(self, cfg: FrontendConfig, layout: str = "b1tm", melW: Optional[torch.Tensor] = None):
+    def __init__(self, cfg: FrontendConfig, layout: str = "b1tm", melW: Optional[torch.Tensor] = None,
+                 mel_owner: Optional[nn.Module] = None, stft: Optional[nn.Module] = None):
         super().__init__()
         if layout not in ("b1tm", "btm", "bmt"):
             raise ValueError(layout)
         self.cfg, self.layout = cfg, layout
-        self.melW = nn.Parameter(mel_filterbank(cfg) if melW is None else melW.detach().clone().float().cpu(),
-                                 requires_grad=False)
-        self.register_buffer("affine_scale", None)
-        self.register_buffer("affine_shift", None)
+        if mel_owner is None:
+            self.melW = nn.Parameter(mel_filterbank(cfg) if melW is None else melW.detach().clone().float().cpu(),
+                                     requires_grad=False)
+        else:
+            # the mel matrix stays a parameter of another module (so that its state_dict key does not move); kept
+            # out of this module's registry, or the key would appear twice
+            object.__setattr__(self, "_mel_owner", mel_owner)
+        if stft is not None:
+            # the windowed-DFT weights a torchlibrosa checkpoint holds under spectrogram_extractor.stft.*: carried
+            # for the state_dict keys and checked on load; the kernel has its own twiddle tables
+            self.stft = stft
+            self.n_fft, self.win_length = cfg.n_fft, cfg.win_length
+            self.register_load_state_dict_post_hook(_check_stft_tables)
+        # eval-mode bn0 folded into the epilogue: derived from bn0's own entries, so not part of the state_dict
+        self.register_buffer("affine_scale", None, persistent=False)
+        self.register_buffer("affine_shift", None, persistent=False)
         self._affine_version = 0
+
+    def _mel(self) -> torch.Tensor:
+        owner = self.__dict__.get("_mel_owner")
+        return self.melW if owner is None else owner.melW
 
     @classmethod
     def from_torchlibrosa(cls, spectrogram_extractor: Spectrogram, logmel_extractor: LogmelFilterBank,
-                          layout: str = "b1tm") -> "LogMelFrontend":
+                          layout: str = "b1tm", mel_owner: Optional[nn.Module] = None,
+                          keep_stft: bool = False) -> "LogMelFrontend":
         """Fuse a Spectrogram + LogmelFilterBank pair (as held by HTSAT_Swin_Transformer) into one module."""
         s, m = spectrogram_extractor, logmel_extractor
         if s.power != 2.0 or not m.is_log or m.top_db is not None or s.n_fft != m.n_fft:
@@ -366,7 +389,8 @@ class LogMelFrontend(_PlanHolder):
                              L.PAD_REFLECT if s.pad_mode == "reflect" else L.PAD_CONSTANT, n_mels=m.n_mels,
                              fmin=float(m.fmin), fmax=float(m.fmax), log_kind=L.LOG_DB10, amin=float(m.amin),
                              ref=float(m.ref))
-        return cls(cfg, layout, melW=m.melW)
+        return cls(cfg, layout, melW=None if mel_owner is not None else m.melW, mel_owner=mel_owner,
+                   stft=s.stft if keep_stft else None)
 
     def set_affine(self, scale: Optional[torch.Tensor], shift: Optional[torch.Tensor]) -> None:
         self.affine_scale = None if scale is None else scale.detach().clone().float()
@@ -384,10 +408,11 @@ class LogMelFrontend(_PlanHolder):
         return self.cfg
 
     def _tables_version(self):
-        return (self.melW._version, self._affine_version)
+        mel = self._mel()
+        return (id(mel), mel._version, self._affine_version)
 
     def _sync_plan(self, plan: _Plan) -> None:
-        plan.set_mel_weights(self.melW)
+        plan.set_mel_weights(self._mel())
         plan.set_affine(self.affine_scale, self.affine_shift)
 
     def num_frames(self, n_samples: int, device=None) -> int:
@@ -406,17 +431,30 @@ class LogMelFrontend(_PlanHolder):
         return out
 
 
-class _Identity(nn.Module):
+class _LogmelPassthrough(nn.Module):
+    """Stands where logmel_extractor stood once the fused kernel has taken over its work: forward is the identity,
+    and it still owns `melW`, so a checkpoint's logmel_extractor.melW keeps loading into the matrix the kernel uses."""
+
+    def __init__(self, melW: torch.Tensor):
+        super().__init__()
+        self.melW = nn.Parameter(melW.detach().clone(), requires_grad=False)
+
     def forward(self, x):
         return x
 
 
 def install_fused_frontend(model: nn.Module) -> nn.Module:
     """Swap model.spectrogram_extractor / model.logmel_extractor (the attributes HTSAT_Swin_Transformer.forward
-    calls at htsat.py:763-764) for the fused kernel + an identity, leaving forward() untouched."""
-    fused = LogMelFrontend.from_torchlibrosa(model.spectrogram_extractor, model.logmel_extractor)
+    calls at htsat.py:763-764) for the fused kernel + an identity, leaving forward() untouched.
+
+    The state_dict keys do not change (spectrogram_extractor.stft.conv_real.weight, ...conv_imag.weight,
+    logmel_extractor.melW), so this may be called before or after the strict load_state_dict of a reference
+    checkpoint (src/models/htsat/model.py:159-162): a mel matrix loaded afterwards is the one the kernel uses."""
+    s, m = model.spectrogram_extractor, model.logmel_extractor
+    holder = _LogmelPassthrough(m.melW)
+    fused = LogMelFrontend.from_torchlibrosa(s, m, mel_owner=holder, keep_stft=True)
     model.spectrogram_extractor = fused
-    model.logmel_extractor = _Identity()
+    model.logmel_extractor = holder
     return model
 
 

@@ -27,9 +27,11 @@ def cut_events(pcm: torch.Tensor, sr, events: Sequence[Tuple[int, float, float]]
         raise RuntimeError(f"cut_events: pcm is on {pcm.device}; the hand-off runs only on a ROCm device")
     if pcm.dim() != 2 or pcm.dtype not in (torch.float32, torch.int16):
         raise RuntimeError("cut_events: expected a (streams, samples) fp32 or int16 tensor")
-    if pcm.stride(1) != 1:
-        pcm = pcm.contiguous()
     S, n = pcm.shape
+    # rows must be sample-contiguous and must not overlap: an expanded clip or an as_strided / unfold view has
+    # stride(0) < n, which the kernel would index as if rows were n apart
+    if pcm.stride(1) != 1 or (S > 1 and pcm.stride(0) < n):
+        pcm = pcm.contiguous()
     idx = np.array([int(e[0]) for e in events], dtype=np.int32)
     start = np.array([int(e[1] * sr) for e in events], dtype=np.int64)     # cut_audio.py:37-38
     end = np.array([int(e[2] * sr) for e in events], dtype=np.int64)

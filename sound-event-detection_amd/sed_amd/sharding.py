@@ -8,7 +8,7 @@ gloo on CPU tensors in the tests).
 """
 from __future__ import annotations
 
-from typing import List, Tuple
+from typing import List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -23,42 +23,68 @@ def shard_bounds(n_items: int, rank: int, world_size: int) -> Tuple[int, int]:
     return lo, lo + q + (1 if rank < r else 0)
 
 
-def pack_events(runs: torch.Tensor, counts: torch.Tensor, cap: int, first_stream: int) -> torch.Tensor:
-    """runs (S, C, cap_in, 2), counts (S, C) -> records int32 (S, cap, 4) = (stream, class, onset, offset), and the
-    per-stream number of records in column 0 of an extra leading row: returns (S, cap + 1, 4).
+def pack_events(runs: torch.Tensor, counts: Optional[torch.Tensor] = None, cap: int = 64, first_stream: int = 0) -> torch.Tensor:
+    """Per-stream event records for the exchange between GPUs, formed on the device in one launch (no host
+    synchronisation, fixed shapes, so the step can be captured in a HIP graph).
 
-    Row 0 of every stream is (n_records, n_dropped, 0, 0); records are class-major, onset-ascending, i.e. the
-    order decode_predictions emits.  Events beyond `cap` per stream are dropped and counted.
+    runs (S, C, cap_in, 2) with counts (S, C), as threshold_runs / merge_runs return them, or the packed
+    (S, C, 1 + 2*cap_in) buffer of threshold_merge_runs with counts=None.  Returns int32 (S, cap + 1, 4): row 0 of
+    every stream is (n_records, n_dropped, 0, 0), rows 1.. are (stream, class, onset frame, offset frame) records,
+    class-major and onset-ascending, i.e. the order decode_predictions emits (src/models/crnn/utils.py:99-134).
+    Events beyond `cap` per stream are dropped and counted.
     """
-    S, C, cap_in, _ = runs.shape
-    dev = runs.device
-    slot = torch.arange(cap_in, device=dev)[None, None, :]
-    valid = slot < counts[:, :, None].clamp(max=cap_in)                              # (S, C, cap_in)
-    n_per_class = valid.sum(-1)                                                       # (S, C)
-    class_base = torch.cumsum(n_per_class, 1) - n_per_class                           # exclusive prefix over classes
-    pos = class_base[:, :, None] + slot                                               # record index inside the stream
-    keep = valid & (pos < cap)
-    out = torch.zeros((S, cap + 1, 4), dtype=torch.int32, device=dev)
-    total = n_per_class.sum(1)
-    out[:, 0, 0] = total.clamp(max=cap).to(torch.int32)
-    out[:, 0, 1] = (total - total.clamp(max=cap)).to(torch.int32)
-    s_idx, c_idx, k_idx = torch.nonzero(keep, as_tuple=True)
-    p_idx = pos[s_idx, c_idx, k_idx] + 1
-    out[s_idx, p_idx, 0] = (s_idx + first_stream).to(torch.int32)
-    out[s_idx, p_idx, 1] = c_idx.to(torch.int32)
-    out[s_idx, p_idx, 2] = runs[s_idx, c_idx, k_idx, 0]
-    out[s_idx, p_idx, 3] = runs[s_idx, c_idx, k_idx, 1]
+    from . import _lib as L
+    if not runs.is_cuda:
+        raise RuntimeError("pack_events runs on a ROCm device: there is no CPU path")
+    if runs.dtype != torch.int32:
+        raise TypeError("runs must be int32")
+    runs = runs.contiguous()
+    if counts is None:
+        if runs.dim() != 3 or runs.shape[2] % 2 != 1:
+            raise ValueError("packed buffer must be (S, C, 1 + 2*cap_in)")
+        S, C, w = runs.shape
+        cap_in, stride = (w - 1) // 2, w
+        runs_ptr, counts_ptr, runs_stride, counts_stride = runs.data_ptr() + 4, runs.data_ptr(), stride, stride
+    else:
+        if runs.dim() != 4 or runs.shape[3] != 2 or tuple(counts.shape) != tuple(runs.shape[:2]):
+            raise ValueError("runs must be (S, C, cap_in, 2) and counts (S, C)")
+        if counts.dtype != torch.int32 or counts.device != runs.device:
+            raise TypeError("counts must be int32 on the device of runs")
+        counts = counts.contiguous()
+        S, C, cap_in, _ = runs.shape
+        runs_ptr, counts_ptr, runs_stride, counts_stride = runs.data_ptr(), counts.data_ptr(), 2 * cap_in, 1
+    out = torch.empty((S, cap + 1, 4), dtype=torch.int32, device=runs.device)
+    with torch.cuda.device(runs.device):
+        L.check(L.lib.sed_pack_events(runs_ptr, runs_stride, counts_ptr, counts_stride, S, C, cap_in, int(first_stream),
+                                      out.data_ptr(), int(cap), L.stream_ptr(runs.device)), "sed_pack_events")
     return out
 
 
-def all_gather_events(packed: torch.Tensor, group=None, async_op: bool = False):
-    """All ranks hold the same number of streams (pad the last shard): (S, cap+1, 4) -> (world*S, cap+1, 4)."""
+def all_gather_events(packed: torch.Tensor, group=None, async_op: bool = False, force_collective: bool = False):
+    """All ranks hold the same number of streams (pad the last shard): (S, cap+1, 4) -> (world*S, cap+1, 4).
+    With one rank nothing is exchanged unless force_collective is set (tests run the collective on a one-rank group)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
+    if world == 1 and not (force_collective and dist.is_initialized()):
         return (packed, None) if async_op else packed
     out = torch.empty((world * packed.shape[0],) + tuple(packed.shape[1:]), dtype=packed.dtype, device=packed.device)
     work = dist.all_gather_into_tensor(out, packed.contiguous(), group=group, async_op=async_op)
     return (out, work) if async_op else out
+
+
+def decode_and_exchange(det_probs: torch.Tensor, time_table: torch.Tensor, gap: float, cap: int = 64,
+                        first_stream: int = 0, threshold: float = 0.5, smoothing: str = "median3", group=None,
+                        async_op: bool = False, force_collective: bool = False, host_staging: bool = False):
+    """The detector-side tail of one batch on one rank, all on the device and without host synchronisation:
+    smoothing + threshold + run extraction + gap merge (src/models/yamnet_train.py:55-71, src/utils/merge_events.py:36-55)
+    of this rank's streams in one launch, the (stream, class, onset, offset) records in a second, then the all-gather
+    of the record buffers.  det_probs (S, T, C) fp32 on the device; returns what all_gather_events returns.
+    host_staging copies the records to the host before the collective (for backends without a device path)."""
+    from . import decode as D
+    buf = D.threshold_merge_runs(det_probs, threshold, time_table, gap, smoothing)   # (S, C, 1 + 2*cap_in): count, runs
+    records = pack_events(buf, None, cap, first_stream)
+    if host_staging and dist.is_initialized() and dist.get_world_size(group) > 1:
+        records = records.cpu()          # rehearsals on a backend without a device path (gloo)
+    return all_gather_events(records, group=group, async_op=async_op, force_collective=force_collective)
 
 
 def unpack_events(gathered: torch.Tensor) -> List[List[Tuple[int, int, int, int]]]:

@@ -71,6 +71,15 @@ def test_host_tables_match_oracle():
     assert np.all(wl[400:] == 0) and np.max(np.abs(wl[:400] - of.hann_periodic(400))) < 1e-7
     wc = sed_amd.hann_window(2048, 1024).numpy()
     assert np.max(np.abs(wc - of.pad_center(of.hann_periodic(1024), 2048))) < 1e-7
+    # bit for bit against the call torchlibrosa / librosa make (scipy get_window, fp64, cast to fp32 with the weights)
+    from scipy.signal import get_window
+    for n in (400, 512, 800, 1024, 1102, 1764, 2048):
+        n_fft = 1 << (n - 1).bit_length()
+        sw = get_window("hann", n, fftbins=True)
+        assert np.array_equal(sed_amd.hann_window(n_fft, n, 1).numpy()[:n], sw.astype(np.float32)), n
+        assert np.array_equal(of.hann_periodic(n), sw)
+        ss = get_window("hann", n, fftbins=False)
+        assert np.array_equal(sed_amd.hann_window(n_fft, n, 1, 1).numpy()[:n], ss.astype(np.float32)), n
 
 
 def test_modules_construct_and_refuse_cpu_input():

@@ -96,6 +96,19 @@ def test_full_crnn_chain_on_synthetic_probabilities(kat):
         assert sed_amd.merge_close_events_batch(got, thr) == {k: od.merge_close_events(v, thr) for k, v in want.items()}
 
 
+def test_decode_predictions_rounding_at_other_frame_rates(golden_dir):
+    """The reference's own outputs at eight frame rates (numpy rounding of np.int64 * float), every frame a boundary."""
+    import sed_amd
+    z = np.load(os.path.join(golden_dir, "d3_rounding.npz"))
+    T = int(z["T"])
+    act = np.zeros((1, T, 1), dtype=int)
+    act[0, 0::2, 0] = 1
+    for i, fps in enumerate(z["fps"]):
+        ev = sed_amd.decode_predictions(act, ["f.wav"], {0: "e"}, float(fps))["f.wav"]
+        assert [e["event_onset"] for e in ev] == z[f"on_{i}"].tolist(), fps
+        assert [e["event_offset"] for e in ev] == z[f"off_{i}"].tolist(), fps
+
+
 def test_gaussian_threshold_bits_near_the_threshold(golden_dir):
     """Traces built to sit within a few ulp of 0.5 after smoothing: the activity must match scipy's bits."""
     import sed_amd

@@ -276,6 +276,42 @@ def test_reshape_wav2img_against_restatement():
         assert np.max(np.abs(im.cpu().numpy() - want)) <= 1e-6 * np.max(np.abs(xl)) * 2
 
 
+def test_reference_htsat_operating_point_44k1_20s_spec512():
+    """The configuration the reference itself runs (src/models/htsat/model.py:171-186 on top of
+    external/hts_audio_transformer/config.py:53-59): 44.1 kHz, 20 s clips, htsat_spec_size 512 -> L = 882000 samples,
+    T = 2757 frames of 64 mel, then reshape_wav2img with freq_ratio 512 // 64 = 8 interpolates to 4096 frames and folds
+    them into a 512 x 512 image (external/hts_audio_transformer/model/htsat.py:729-744)."""
+    import sed_amd
+    dev = _dev()
+    sr, L = 44100, 882000
+    x = of.synth_batch(2, L, sr, first=40)
+    fe = sed_amd.LogMelFrontend(sed_amd.FrontendConfig.htsat(sample_rate=sr))
+    y = fe(torch.from_numpy(x).to(dev))
+    assert y.shape == (2, 1, 2757, 64)
+    yn = y.cpu().numpy()
+    _check(yn, of.htsat_logmel(x, sr=sr, mode="gold"), of.htsat_logmel(x, sr=sr, mode="ref32"), NEAR_DB)
+    img = sed_amd.reshape_wav2img(y, 512, 8)
+    assert img.shape == (2, 1, 512, 512)
+    want = of.htsat_reshape_wav2img(yn, 512, 8)
+    assert np.max(np.abs(img.cpu().numpy() - want)) <= 1e-6 * np.max(np.abs(yn)) * 2
+    assert torch.equal(sed_amd.reshape_wav2img(y, 512), img)           # freq_ratio defaults to spec_size // mel bins
+    with pytest.raises(AssertionError):                                # 2757 frames do not fit the 256-size model
+        sed_amd.reshape_wav2img(y)
+    # the detector-side decode of the same operating point: (1, 4096, 6) framewise map, 20 s clip (combined.py:17-73)
+    rng = np.random.default_rng(8)
+    pm = rng.random((1, 4096, 6), dtype=np.float32)
+    from oracle import decode as od
+    names = ["cough", "dog_bark", "gun_shot", "siren", "car_horn", "non_event"]
+    lab = np.repeat(rng.integers(0, 6, 4096 // 300 + 1), 300)[:4096]
+    pm[0, np.arange(4096), lab] += 0.6
+
+    class Cfg:
+        clip_duration = 20.0
+    want_ev = od.htsat_events_from_batch(["a.wav"], pm, names, 5, 20.0)
+    got_ev = sed_amd.get_events_from_batch({"file": ["a.wav"], "pred_map": torch.from_numpy(pm).to(dev)}, Cfg)
+    assert got_ev == want_ev and len(want_ev["a.wav"]) >= 5
+
+
 def test_repeat_mode_and_infer_mode_images():
     """enable_repeat_mode (htsat.py:747-760, 789-793) and infer_mode (:775-781) image builders vs the restatement."""
     import sed_amd
@@ -341,6 +377,26 @@ def test_state_dict_and_install_on_reference_shaped_model():
     fused.set_batchnorm(m.bn0)                                           # bn0 folded into the kernel epilogue
     assert torch.max(torch.abs(fused(x) - want)).item() < 1e-4
     fused.set_affine(None, None)
+    # the keys did not move: a checkpoint saved from the unfused pair loads strictly AFTER the install too, which is the
+    # order init_model uses (construct, then load_state_dict: src/models/htsat/model.py:151-162), and the mel matrix it
+    # carries is the one the fused kernel then applies
+    assert set(m.state_dict()) == keys
+    fresh = Host().to(dev).eval()
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    sd2["logmel_extractor.melW"] = sd["logmel_extractor.melW"] * 0.5     # a checkpoint with its own mel matrix
+    fresh.load_state_dict(sd2, strict=True)
+    want2 = fresh(x)
+    m.load_state_dict(sd2, strict=True)
+    got2 = m(x)
+    assert torch.max(torch.abs(got2 - want2)).item() < 1e-4
+    assert torch.max(torch.abs(got2 - got)).item() > 0.1                  # (halving the matrix moves every value by 3 dB / sigma)
+    late = sed_amd.install_fused_frontend(Host().to(dev).eval())         # install first, load second
+    late.load_state_dict(sd2, strict=True)
+    assert torch.equal(late(x), got2)
+    bad = {k: v.clone() for k, v in sd2.items()}
+    bad["spectrogram_extractor.stft.conv_real.weight"] = bad["spectrogram_extractor.stft.conv_real.weight"] * 1.01
+    with pytest.raises(RuntimeError):
+        late.load_state_dict(bad, strict=True)
 
 
 def test_full_size_properties_config2():

@@ -45,6 +45,29 @@ def test_cut_events_matches_numpy_slices():
         sed_amd.cut_events(torch.from_numpy(x), sr, events)
 
 
+def test_cut_events_views_with_overlapping_or_repeated_rows():
+    """Views whose rows are less than a row length apart (one clip expanded to several streams, overlapping windows of
+    a long recording, a column slice of a wider batch) must be read as the tensor they present."""
+    import sed_amd
+    dev = torch.device("cuda", 0)
+    sr = 16000
+    long = torch.from_numpy(of.synth_batch(1, 6 * sr, sr, first=97)[0]).to(dev)
+    events = [(0, 0.1, 0.9), (1, 0.0, 1.5), (2, 1.0, 2.0), (3, 0.25, 1.75), (2, 1.9, 2.5)]
+    views = {
+        "expand": long[:2 * sr][None].expand(4, -1),                              # stride(0) == 0
+        "unfold": long.unfold(0, 2 * sr, sr // 2)[:4],                             # windows of 2 s, 0.5 s apart
+        "as_strided": torch.as_strided(long, (4, 2 * sr), (123, 1)),
+        "columns": long[:4 * (sr + 5)].reshape(4, sr + 5)[:, 3:sr],               # stride(0) > row length
+        "single": long[None, :2 * sr],
+    }
+    for name, v in views.items():
+        ev = [e for e in events if e[0] < v.shape[0]]
+        clips, lens = sed_amd.cut_events(v, sr, ev)
+        want, wl = _expected(v.cpu().numpy(), sr, ev, clips.shape[1])
+        assert np.array_equal(lens.cpu().numpy(), wl), name
+        assert np.array_equal(clips.cpu().numpy(), want), name
+
+
 def test_cut_events_from_audio_names_and_rows():
     import sed_amd
     dev = torch.device("cuda", 0)

@@ -57,6 +57,24 @@ def test_decode_predictions_roundtrip(kat, golden_dir):
     assert np.array_equal(on, a["fps_cur_on"]) and np.array_equal(off, a["fps_cur_off"])
 
 
+def test_decode_predictions_rounding_at_other_frame_rates(golden_dir):
+    """d3_rounding.npz: the reference's decode_predictions at eight frame rates, every frame index a boundary.  The
+    reference rounds an np.float64 (numpy's rint(x * 1000) / 1000), which differs from rounding a Python float for
+    thousands of (frame, rate) pairs: at 2000 frames/s frame 1 is 0.0, not 0.001."""
+    z = np.load(os.path.join(golden_dir, "d3_rounding.npz"))
+    T = int(z["T"])
+    act = np.zeros((1, T, 1), dtype=int)
+    act[0, 0::2, 0] = 1
+    n_python_differs = 0
+    for i, fps in enumerate(z["fps"]):
+        ev = od.decode_predictions(act, ["f.wav"], {0: "e"}, float(fps))["f.wav"]
+        assert [e["event_onset"] for e in ev] == z[f"on_{i}"].tolist()
+        assert [e["event_offset"] for e in ev] == z[f"off_{i}"].tolist()
+        res = 1.0 / float(fps)
+        n_python_differs += sum(round(k * res, 3) != v for k, v in zip(range(1, T + 1, 2), z[f"off_{i}"].tolist()))
+    assert n_python_differs > 0
+
+
 def test_yamnet_stage2_quantisation(golden_dir):
     z = np.load(os.path.join(golden_dir, "yamnet_stage2_times.npz"))
     grid = np.arange(0, 43) * 0.48

@@ -1,6 +1,8 @@
-"""Multi-rank path on CPU: two gloo ranks shard the stream batch, decode their block (with the oracle standing in
-for the GPU kernels' output format) and all-gather fixed-size event buffers; every rank must end up with the events
-of the whole batch in stream order, identical to a single-process decode."""
+"""Multi-rank path on CPU: two gloo ranks shard the stream batch, decode their block and form the event records (the
+oracle stands in for the GPU kernels, which have no CPU path: threshold_runs' output layout and pack_events' record
+format) and all-gather the fixed-size record buffers; every rank must end up with the events of the whole batch in
+stream order, identical to a single-process decode.  The GPU side of the same path (the HIP pack kernel against this
+oracle, gathered over RCCL) is tests/test_gpu_sharding.py."""
 import os
 import socket
 
@@ -44,7 +46,7 @@ def _worker(rank, world, port, n_streams, cap, out_dir):
     mine = np.zeros((per_rank,) + probs.shape[1:], np.float32)           # last shard padded with silent streams
     mine[:hi - lo] = probs[lo:hi]
     runs, counts = _runs_from_oracle(mine, 0.5, probs.shape[1] // 2 + 1)
-    packed = sharding.pack_events(runs, counts, cap, first_stream=rank * per_rank)
+    packed = torch.from_numpy(od.pack_events(runs.numpy(), counts.numpy(), cap, first_stream=rank * per_rank))
     gathered, work = sharding.all_gather_events(packed, async_op=True)
     work.wait()
     torch.save(gathered, os.path.join(out_dir, f"rank{rank}.pt"))
