@@ -168,11 +168,11 @@ int main() {
     report(512, "magnitude/left400", run_one<Geo<16, 16, 8, 12>, true>(seed, 400, true));
     report(512, "power", run_one<Geo<16, 16, 8, 12>, false>(seed, 512, false));
     report(1024, "power", run_one<Geo<32, 16, 16, 12>, false>(seed, 1024, false));
-    report(2048, "magnitude", run_one<Geo<32, 32, 16, 4>, true>(seed, 2048, false));
-    report(2048, "power", run_one<Geo<32, 32, 16, 4>, false>(seed, 2048, false));
+    report(2048, "magnitude", run_one<Geo<32, 32, 16, 8>, true>(seed, 2048, false));
+    report(2048, "power", run_one<Geo<32, 32, 16, 8>, false>(seed, 2048, false));
   }
   report(512, "kaldi framing 400", run_conditioned<Geo<16, 16, 8, 12>>(7, 400, 0.97f));
   report(1024, "kaldi framing 800", run_conditioned<Geo<32, 16, 16, 12>>(8, 800, 0.97f));
-  report(2048, "kaldi framing 1102", run_conditioned<Geo<32, 32, 16, 4>>(9, 1102, 0.97f));
+  report(2048, "kaldi framing 1102", run_conditioned<Geo<32, 32, 16, 8>>(9, 1102, 0.97f));
   return bad;
 }

@@ -29,10 +29,14 @@ namespace sed {
 
 using Geo512 = Geo<16, 16, 8, 12>;
 using Geo1024 = Geo<32, 16, 16, 12>;
-using Geo2048 = Geo<32, 32, 16, 4>;
+using Geo2048 = Geo<32, 32, 16, 8>;
 
 #if defined(SED_TIMELINE) || defined(SED_X_MASK) || defined(SED_STAMPS)
 #define SED_DIAGNOSTIC_BUILD 1  // diagnostic builds read SED_DEBUG_WAVES from the environment
+#endif
+
+#ifndef SED_WPE
+#define SED_WPE(x) (x)   // experiments: -DSED_WPE(x)=4 asks the register allocator for 4 wavefronts per SIMD
 #endif
 
 constexpr int kMaxMelSets = 4;
@@ -335,6 +339,12 @@ __device__ __forceinline__ void mel_store(const FrontParams& p, float* dst, v4 v
   }
 }
 
+// Wavefronts per workgroup (= per CU).  The spectrogram-output kernels (the unfused parity path) keep a few more values
+// live and get 8 wavefronts with 256 registers each instead of 12 with 168: no spills, and their rate is set by the
+// (T, F) writes anyway.
+template <class G, bool SPEC_OUT>
+constexpr int wg_waves_of() { return SPEC_OUT && G::WAVES > 8 ? 8 : G::WAVES; }
+
 // Work distribution.  A group is FPW consecutive frames of one clip.  Every workgroup owns a contiguous range of
 // groups (so a CU streams through contiguous PCM); its wavefronts take them one at a time from a counter in LDS.
 // The hardware issues instructions oldest-wavefront-first, so wavefronts with equal static shares finish far
@@ -342,7 +352,8 @@ __device__ __forceinline__ void mel_store(const FrontParams& p, float* dst, v4 v
 // queue they all stay busy until the range is drained.  The span of the next group is ordered as soon as the current
 // one's power rows are consumed, whichever clip it belongs to.
 template <class G, bool MAG, bool SPEC_OUT, bool PRE, bool I16, class Mel>
-__global__ void __launch_bounds__(G::WAVES * 64) __attribute__((amdgpu_waves_per_eu(G::WAVES / 4, G::WAVES / 4)))
+__global__ void __launch_bounds__((wg_waves_of<G, SPEC_OUT>()) * 64)
+__attribute__((amdgpu_waves_per_eu(SED_WPE((wg_waves_of<G, SPEC_OUT>()) / 4), SED_WPE((wg_waves_of<G, SPEC_OUT>()) / 4))))
 stft_mel_kernel(const FrontParams p) {
   extern __shared__ __align__(16) float smem[];
 #ifdef SED_TIMELINE
@@ -903,7 +914,7 @@ static int launch_front_shape(const sed_plan* pl, FrontParams p, int64_t B, hipS
   p.off_queue = p.image_floats;
   p.off_wave = round64(p.off_queue + 4);
   // as many wavefronts per workgroup as the geometry allows and LDS holds
-  int waves = G::WAVES;
+  int waves = wg_waves_of<G, SPEC_OUT>();
 #ifdef SED_DIAGNOSTIC_BUILD
   static const int debug_waves = getenv("SED_DEBUG_WAVES") ? atoi(getenv("SED_DEBUG_WAVES")) : 0;
   if (debug_waves > 0) waves = std::min(waves, debug_waves);
