@@ -194,17 +194,24 @@ __device__ __forceinline__ void stage_span(const FrontParams& p, float* dst, int
 // destination together).  Completion: vmcnt.
 __device__ __forceinline__ void stage_span_dma(const FrontParams& p, float* dst, int64_t b, int64_t s0, int lane) {
   const float* src = (const float*)p.pcm + b * p.pcm_stride + s0 + 4 * lane;
-  static_for<0, kMaxSpanBlocks / 4>([&](auto Qf) {
-    constexpr int q = decltype(Qf)::value;
-    if (4 * q < p.span_blocks) {  // wave-uniform
-      const auto* gs = (const __attribute__((address_space(1))) void*)(src + 1024 * q);
-      auto* ld = (__attribute__((address_space(3))) void*)(dst + 1024 * q);
-      __builtin_amdgcn_global_load_lds(gs, ld, 16, 0, 0);
-      if (4 * q + 1 < p.span_blocks) __builtin_amdgcn_global_load_lds(gs, ld, 16, 1024, 0);
-      if (4 * q + 2 < p.span_blocks) __builtin_amdgcn_global_load_lds(gs, ld, 16, 2048, 0);
-      if (4 * q + 3 < p.span_blocks) __builtin_amdgcn_global_load_lds(gs, ld, 16, 3072, 0);
-    }
-  });
+  // a rolled loop over groups of four blocks keeps the scalar state to a pointer pair and a counter
+  int left = p.span_blocks;
+#pragma nounroll
+  for (; left >= 4; left -= 4, src += 1024, dst += 1024) {
+    const auto* gs = (const __attribute__((address_space(1))) void*)src;
+    auto* ld = (__attribute__((address_space(3))) void*)dst;
+    __builtin_amdgcn_global_load_lds(gs, ld, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(gs, ld, 16, 1024, 0);
+    __builtin_amdgcn_global_load_lds(gs, ld, 16, 2048, 0);
+    __builtin_amdgcn_global_load_lds(gs, ld, 16, 3072, 0);
+  }
+  if (left > 0) {
+    const auto* gs = (const __attribute__((address_space(1))) void*)src;
+    auto* ld = (__attribute__((address_space(3))) void*)dst;
+    __builtin_amdgcn_global_load_lds(gs, ld, 16, 0, 0);
+    if (left > 1) __builtin_amdgcn_global_load_lds(gs, ld, 16, 1024, 0);
+    if (left > 2) __builtin_amdgcn_global_load_lds(gs, ld, 16, 2048, 0);
+  }
 }
 
 // Shape of a plan's mel schedule.  The shapes of the reference's own flavours are compiled in, which turns the
@@ -386,6 +393,7 @@ stft_mel_kernel(const FrontParams p) {
   const int g_end = (int)((int64_t)p.total_groups * (blockIdx.x + 1) / gridDim.x);
 #ifdef SED_TIMELINE
   const unsigned long long tl_loop = __builtin_amdgcn_s_memrealtime();
+  int tl_iters = 0;
 #endif
   constexpr int kGroups = G::FPW / 4;
   int gi = g_begin + wave;
@@ -401,6 +409,9 @@ stft_mel_kernel(const FrontParams p) {
     int hvalid = 0;
     SED_STAMP_DECL
     while (true) {
+#ifdef SED_TIMELINE
+      ++tl_iters;
+#endif
       // take the next group now; the answer is needed when its span is ordered, half an iteration from here
       int taken = 0;
       if (lane == 0) taken = atomicAdd(qhead, 1);
@@ -523,7 +534,7 @@ stft_mel_kernel(const FrontParams p) {
     unsigned long long* o = p.stamps + (size_t)(blockIdx.x * wg_waves + wave) * 4;
     o[0] = tl_start; o[1] = tl_loop; o[2] = __builtin_amdgcn_s_memrealtime();
     unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    o[3] = ((unsigned long long)xcc << 32);
+    o[3] = ((unsigned long long)xcc << 32) | (unsigned)(tl_iters & 0xffff);
   }
 #endif
 }
@@ -974,6 +985,14 @@ static int launch_front_shape(const sed_plan* pl, FrontParams p, int64_t B, hipS
     const double nw = (double)(n_tl / 4);
     fprintf(stderr, "TIMELINE waves %zu  span %.2f us  mean start %.2f (max %.2f)  mean setup %.2f  mean end %.2f (min %.2f)  mean residency %.2f us\n",
             n_tl / 4, (t1 - t0) * 0.01, sum_start / nw, max_start, sum_setup / nw, sum_end / nw, min_end, sum_res / nw);
+    {
+      double iters = 0; int max_iters = 0, min_iters = 1 << 30;
+      for (size_t w = 0; w < n_tl / 4; ++w) {
+        const int it = (int)(h[w * 4 + 3] & 0xffff);
+        iters += it; max_iters = std::max(max_iters, it); min_iters = std::min(min_iters, it);
+      }
+      fprintf(stderr, "TIMELINE groups per wave %.2f (min %d, max %d)\n", iters / nw, min_iters, max_iters);
+    }
     for (int x = 0; x < 8; ++x) if (xn[x]) fprintf(stderr, "TIMELINE xcc %d: waves %d mean end %.2f max end %.2f\n", x, xn[x], xe[x] / xn[x], xmax[x]);
     int hist[20] = {0};
     for (size_t w = 0; w < n_tl / 4; ++w) { int bb = (int)((h[w * 4 + 2] - t0) * 0.01 / ((t1 - t0) * 0.01) * 20); hist[std::min(bb, 19)]++; }
@@ -1076,6 +1095,7 @@ static int front_forward(const sed_plan* pl, const void* pcm, int64_t B, int64_t
   p.mel_maxpos = pl->mel_maxpos;
   p.n_quads = pl->n_quads;
   p.dma = (c.pcm_kind == SED_PCM_F32) && ((uintptr_t)pcm % 16 == 0) && (pcm_stride % 4 == 0) && (c.hop % 4 == 0) ? 1 : 0;  // n_fft/2: a multiple of 4
+  if (SED_SKIP(2048)) p.dma = 0;  // experiment: register-staged spans for fp32 too
   p.out_vec = (c.n_mels % 4 == 0) && ((uintptr_t)out % 16 == 0) && (out_stride_b % 4 == 0) ? 1 : 0;
   hipStream_t s = (hipStream_t)stream;
   const bool mag = c.spectrum == SED_SPEC_MAGNITUDE;
