@@ -148,8 +148,14 @@ struct Geo {
   static constexpr int A = R2 / LPF;        // stage-1 FFTs per lane
   static constexpr int FPW = 64 / LPF;      // frames per wave
   static constexpr int FPI = WAVES * FPW;   // frames per workgroup iteration
-  static constexpr int RP = R1 + 4;         // exchange row pitch in floats (R1/2 complex + pad)
-  static constexpr int XFR = R2 * RP + 32;  // exchange floats per frame
+  // Exchange rows: pitch RP and floats per frame XFR.  The LDS serves an 8-byte access 32 lanes at a time, i.e. 32 / LPF
+  // frames together; the pads are picked (by enumerating every write and read instruction of the exchange) so that
+  // those lanes fall on distinct banks: none of the accesses of Geo<32,16,16> conflict; in the other two geometries
+  // the writes are conflict free and the reads 2-way.  (With pitch R1 + 4 and a 32-float frame pad the writes of two
+  // frames met on the same banks: 64 % of the kernel's bank-conflict cycles.)
+  static constexpr int RP = R1 + (LPF == 16 ? (R2 == 16 ? 6 : 2) : 4);
+  static constexpr int XFR = R2 * RP + (LPF == 16 ? (R2 == 16 ? 0 : 2) : 10);
+  static_assert(RP % 2 == 0 && XFR % 2 == 0 && RP >= R1, "8-byte accesses, R1/2 complex values per row and phase");
   static constexpr int PP = NC + 16;        // power-row pitch in floats (16 mod 64: the 4 frames of a wave tile the banks)
   static constexpr int SLOTS = R2 + 1;      // split slots per lane (one of them stores from lane 0 only)
   // Lane-major table layouts: the values one lane reads are contiguous, so that it fetches two of them per 16-byte
@@ -378,10 +384,9 @@ SED_HD void lane_xwrite(const LaneState<G>& st, float* xfr, int l) {
       asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(val), "n"(8 * q) : "memory");
     });
 #else
-    static_for<0, G::R1 / 4>([&](auto Q) {
+    static_for<0, G::R1 / 2>([&](auto Q) {
       constexpr int q = decltype(Q)::value;
-      constexpr int k1 = PH * (G::R1 / 2) + 2 * q;
-      st4(row + 4 * q, __builtin_shufflevector(st.y[a][k1], st.y[a][k1 + 1], 0, 1, 2, 3));
+      *reinterpret_cast<v2*>(row + 2 * q) = st.y[a][PH * (G::R1 / 2) + q];
     });
 #endif
   });
