@@ -203,7 +203,7 @@ def main():
                                "(BASELINE.json configs[1]) + detector decode of the same streams",
                    "clips_per_gpu": B_PER_GPU, "device_prewarm_s": PREWARM_S, "samples_per_clip": L, "frames_per_clip": T, "pcm": "f32",
                    "parallelism": f"streams sharded over {world} GPU(s), all-gather of event record buffers",
-                   "step_covers": "fused log-mel kernel + threshold/merge kernel + record kernel (+ all-gather for N > 1), "
+                   "step_covers": "fused log-mel kernel + one decode kernel (median, threshold, runs, gap merge, event records) (+ all-gather for N > 1), "
                                   "all on the device; formatting events as host dictionaries is outside the step",
                    "decode_with_host_formatting_ms": host_fmt_ms,
                    "decode_with_host_formatting_note": "detect_onsets_offsets_batch on the same 256 streams: kernel + "

@@ -222,6 +222,14 @@ int sed_pack_events(const int32_t* runs, int64_t runs_stride, const int32_t* cou
                     int64_t n_streams, int64_t C, int32_t cap_in, int32_t first_stream, int32_t* records,
                     int32_t cap_out, void* stream);
 
+/* sed_threshold_merge_runs followed by sed_pack_events in one launch, with the same records as the two calls give
+ * (detector decode of src/models/yamnet_train.py:55-71, gap merge of src/utils/merge_events.py:36-55, record order of
+ * src/models/crnn/utils.py:99-134): probs fp32 [B][T][C] -> records int32 [B][cap_out + 1][4] as sed_pack_events
+ * lays them out.  T/2 + 1 <= 256 (the raw runs of a trace stay in LDS), else SED_ERR_CAPACITY. */
+int sed_threshold_merge_records(const float* probs, int64_t B, int64_t T, int64_t C, float threshold, int32_t smoothing,
+                                const double* time_table, int32_t table_len, double gap, int32_t first_stream,
+                                int32_t* records, int32_t cap_out, void* stream);
+
 /* ---- detector -> classifier hand-off ----------------------------------------------------------------- */
 
 /* Cuts event e = samples [start, end) of stream ev_stream[e] out of the resident PCM batch into row e of a

@@ -327,6 +327,39 @@ __global__ void __launch_bounds__(256) pack_events_kernel(const int32_t* runs, i
   if (lane == 0) rec[0] = make_int4(kept, base - kept, 0, 0);
 }
 
+// threshold_merge_kernel and pack_events_kernel in one launch: one wavefront per stream walks the stream's classes,
+// raw and merged runs of the class in hand stay in LDS, records go out 64 at a time.
+__global__ void __launch_bounds__(256) threshold_merge_records_kernel(const float* probs, int64_t n_streams, int T, int C,
+                                                                      float thr, int smoothing, const double* table,
+                                                                      int table_len, double gap, int first_stream,
+                                                                      int32_t* records, int cap_out) {
+  __shared__ int32_t raw[4][2 * kFusedCap];
+  __shared__ int32_t merged[4][2 * kFusedCap];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t s = (int64_t)blockIdx.x * 4 + w;
+  if (s >= n_streams) return;
+  int4* rec = reinterpret_cast<int4*>(records) + s * (int64_t)(cap_out + 1);
+  int base = 0;
+  for (int c = 0; c < C; ++c) {
+    const int n = threshold_runs_wave(probs + s * (int64_t)T * C + c, T, C, thr, smoothing, raw[w], kFusedCap, lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int n_out = merge_wave<true>(nullptr, nullptr, raw[w], 0, min(n, kFusedCap), table, table_len, gap, nullptr,
+                                       nullptr, merged[w], 0, lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int k = lane; k < n_out && base + k < cap_out; k += 64)
+      rec[1 + base + k] = make_int4((int)s + first_stream, c, merged[w][2 * k], merged[w][2 * k + 1]);
+    base += n_out;
+    __builtin_amdgcn_wave_barrier();  // the next class overwrites both buffers
+  }
+  const int kept = min(base, cap_out);
+  for (int k = kept + lane; k < cap_out; k += 64) rec[1 + k] = make_int4(0, 0, 0, 0);
+  if (lane == 0) rec[0] = make_int4(kept, base - kept, 0, 0);
+}
+
 }  // namespace sed
 
 using namespace sed;
@@ -412,6 +445,20 @@ extern "C" int sed_threshold_merge_runs(const float* probs, int64_t B, int64_t T
   if (!packed || !time_table || (T > 0 && !probs)) return SED_ERR_BAD_ARG;
   hipLaunchKernelGGL(threshold_merge_kernel, dim3(blocks_for(B * C)), dim3(256), 0, (hipStream_t)stream, probs, B * C,
                      (int)T, (int)C, threshold, (int)smoothing, time_table, (int)table_len, gap, packed, (int)cap);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int sed_threshold_merge_records(const float* probs, int64_t B, int64_t T, int64_t C, float threshold,
+                                           int32_t smoothing, const double* time_table, int32_t table_len, double gap,
+                                           int32_t first_stream, int32_t* records, int32_t cap_out, void* stream) {
+  if (B < 0 || T < 0 || C < 0 || cap_out < 1 || smoothing < 0 || smoothing > 2 || table_len < 1) return SED_ERR_BAD_ARG;
+  if (T >= INT32_MAX - 64 || C > INT32_MAX || B + (int64_t)first_stream > INT32_MAX) return SED_ERR_BAD_ARG;
+  if (T / 2 + 1 > kFusedCap) return SED_ERR_CAPACITY;  // every raw run of a trace must fit the LDS buffer
+  if (B == 0) return SED_OK;
+  if (!records || !time_table || (T > 0 && C > 0 && !probs)) return SED_ERR_BAD_ARG;
+  hipLaunchKernelGGL(threshold_merge_records_kernel, dim3(blocks_for(B)), dim3(256), 0, (hipStream_t)stream, probs, B,
+                     (int)T, (int)C, threshold, (int)smoothing, time_table, (int)table_len, gap, (int)first_stream, records,
+                     (int)cap_out);
   return hip_status(hipGetLastError());
 }
 

@@ -72,6 +72,7 @@ SIGNATURES = {
     "sed_merge_events": (C.c_int, [_vp, _vp, _vp, _i64, _f64, _vp, _vp, _vp, _vp]),
     "sed_merge_runs": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _i32, _f64, _vp, _vp, _vp]),
     "sed_threshold_merge_runs": (C.c_int, [_vp, _i64, _i64, _i64, _f32, _i32, _vp, _i32, _f64, _vp, _i32, _vp]),
+    "sed_threshold_merge_records": (C.c_int, [_vp, _i64, _i64, _i64, _f32, _i32, _vp, _i32, _f64, _i32, _vp, _i32, _vp]),
     "sed_pack_events": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _i32, _vp]),
     "sed_htsat_wav2img": (C.c_int, [_vp, _i64, _i64, _i64, _i64, _i32, _vp, _vp]),
     "sed_htsat_repeat2img": (C.c_int, [_vp, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _vp, _vp]),

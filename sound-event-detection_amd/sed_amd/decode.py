@@ -123,6 +123,26 @@ def threshold_merge_runs(probs: torch.Tensor, threshold: float, time_table: torc
     return packed
 
 
+def threshold_merge_records(probs: torch.Tensor, threshold: float, time_table: torch.Tensor, gap: float, smoothing=None,
+                            cap: int = 64, first_stream: int = 0):
+    """threshold_merge_runs and the record packer of the multi-GPU exchange in one launch: probs (S, T, C) fp32 on the
+    device -> int32 (S, cap + 1, 4) records (row 0 = kept, dropped; rows 1.. = stream + first_stream, class, onset
+    frame, offset frame), the same values as sharding.pack_events(threshold_merge_runs(...), None, cap, first_stream)."""
+    if not probs.is_cuda:
+        raise RuntimeError("threshold_merge_records needs device tensors (there is no CPU path)")
+    if probs.dim() != 3 or probs.dtype != torch.float32:
+        raise ValueError("probs must be fp32 (S, T, C)")
+    probs = probs.contiguous()
+    S, T, Cn = probs.shape
+    records = torch.empty((S, cap + 1, 4), dtype=torch.int32, device=probs.device)
+    with torch.cuda.device(probs.device):
+        L.check(L.lib.sed_threshold_merge_records(probs.data_ptr(), S, T, Cn, float(np.float32(threshold)),
+                                                  _SMOOTH[smoothing], time_table.data_ptr(), time_table.numel(),
+                                                  float(gap), int(first_stream), records.data_ptr(), int(cap),
+                                                  L.stream_ptr(probs.device)), "sed_threshold_merge_records")
+    return records
+
+
 def merge_event_groups(onsets: torch.Tensor, offsets: torch.Tensor, group_start: torch.Tensor, gap: float):
     """fp64 onsets/offsets (n,), group_start int32 (G+1,) -> merged onsets, offsets (n,), counts (G,)."""
     G = group_start.numel() - 1

@@ -76,12 +76,12 @@ def decode_and_exchange(det_probs: torch.Tensor, time_table: torch.Tensor, gap: 
                         async_op: bool = False, force_collective: bool = False, host_staging: bool = False):
     """The detector-side tail of one batch on one rank, all on the device and without host synchronisation:
     smoothing + threshold + run extraction + gap merge (src/models/yamnet_train.py:55-71, src/utils/merge_events.py:36-55)
-    of this rank's streams in one launch, the (stream, class, onset, offset) records in a second, then the all-gather
-    of the record buffers.  det_probs (S, T, C) fp32 on the device; returns what all_gather_events returns.
+    of this rank's streams and their (stream, class, onset, offset) records in one launch, then the all-gather of the
+    record buffers.  det_probs (S, T, C) fp32 on the device, T <= 510 (longer traces: threshold_runs + merge_runs +
+    pack_events); returns what all_gather_events returns.
     host_staging copies the records to the host before the collective (for backends without a device path)."""
     from . import decode as D
-    buf = D.threshold_merge_runs(det_probs, threshold, time_table, gap, smoothing)   # (S, C, 1 + 2*cap_in): count, runs
-    records = pack_events(buf, None, cap, first_stream)
+    records = D.threshold_merge_records(det_probs, threshold, time_table, gap, smoothing, cap, first_stream)
     if host_staging and dist.is_initialized() and dist.get_world_size(group) > 1:
         records = records.cpu()          # rehearsals on a backend without a device path (gloo)
     return all_gather_events(records, group=group, async_op=async_op, force_collective=force_collective)

@@ -83,6 +83,47 @@ def test_pack_events_against_oracle_both_input_layouts():
         sed_amd.sharding.pack_events(torch.zeros((2, 1, 4), dtype=torch.int32, device=dev), None, 4)
 
 
+def test_records_in_one_launch_equal_the_two_step_path():
+    """sed_threshold_merge_records against sed_threshold_merge_runs + sed_pack_events (bit exact) and against the oracle's
+    median / threshold / regions / merge / pack chain, several classes, caps that overflow, traces at the LDS limit."""
+    import sed_amd
+    from sed_amd import decode as D
+    dev = _dev()
+    rng = np.random.default_rng(23)
+    for (S, T, C, cap, gap, smoothing) in ((37, 20, 1, 16, 0.6, "median3"), (9, 41, 6, 5, 1.0, None), (130, 96, 5, 16, 0.3, "median3"),
+                                           (1, 3, 2, 1, 0.6, None), (5, 510, 3, 64, 0.5, "gauss"), (3, 1, 1, 4, 0.6, "median3")):
+        probs = rng.random((S, T, C), dtype=np.float32)
+        probs[0] = 0.0
+        if S > 2:
+            probs[2] = 1.0
+        hop = 0.48 if T < 100 else 0.02
+        table_host = [k * hop for k in range(T + 2)]
+        table = torch.tensor(table_host, dtype=torch.float64, device=dev)
+        pt = torch.from_numpy(probs).to(dev)
+        got = D.threshold_merge_records(pt, 0.5, table, gap, smoothing, cap, first_stream=700)
+        two = sed_amd.sharding.pack_events(D.threshold_merge_runs(pt, 0.5, table, gap, smoothing), None, cap, first_stream=700)
+        assert got.shape == (S, cap + 1, 4) and torch.equal(got, two), (S, T, C, cap)
+        if smoothing != "gauss":
+            sm = od.median3_time(probs, 1) if smoothing == "median3" else probs
+            act = (sm > np.float32(0.5)).astype(int)
+            cap_in = T // 2 + 1
+            runs = np.zeros((S, C, cap_in, 2), np.int32)
+            counts = np.zeros((S, C), np.int32)
+            for s_ in range(S):
+                for c in range(C):
+                    ev = [{"file": "f", "event_onset": table_host[a], "event_offset": table_host[b], "event_label": "e", "k": (a, b)}
+                          for a, b in od.contiguous_regions(act[s_, :, c])]
+                    merged = od.merge_close_events(ev, gap)
+                    counts[s_, c] = len(merged)
+                    for k, m in enumerate(merged):
+                        runs[s_, c, k] = (table_host.index(m["event_onset"]), table_host.index(m["event_offset"]))
+            assert np.array_equal(got.cpu().numpy(), od.pack_events(runs, counts, cap, first_stream=700)), (S, T, C, cap)
+    with pytest.raises(ValueError):                                    # 512 frames: one raw run too many for the LDS buffer
+        D.threshold_merge_records(torch.zeros((1, 512, 1), device=dev), 0.5, torch.zeros(514, dtype=torch.float64, device=dev), 0.5)
+    with pytest.raises(RuntimeError):
+        D.threshold_merge_records(torch.zeros((1, 4, 1)), 0.5, torch.zeros(6, dtype=torch.float64), 0.5)
+
+
 def test_exchange_over_rccl_one_rank_group(rccl_group):
     """The function bench.py times (decode -> records -> all-gather), with the collective forced on a one-rank RCCL group."""
     import sed_amd
