@@ -235,12 +235,13 @@ template <class Mel> __device__ __forceinline__ bool mel_two_rounds(const FrontP
 // Lane 4*block + j feeds the power of frame j as the B operand and the weight of filter 4*quad + j as the
 // A operand of block `block`; after the last instruction it holds, in acc[i], the partial sum of filter
 // 4*quad + i for frame j over the bins of position (set, block).  The weight table carries one all-zero step per
-// set, so an odd step count needs no special case.  The partial sums go to LDS, kPartStride floats per position.
+// set, so an odd step count needs no special case.  The partial sums go to LDS, kPartStride floats per slot; which
+// slot a block fills comes from the lane's table word (blocks are placed for bank-conflict-free operand reads, slots
+// follow the quads).
 template <class Mel>
 __device__ __forceinline__ void mel_mfma_4frames(const FrontParams& p, const int32_t* boffL, const float* prow0,
                                                  const float* mela, float* part, int lane) {
   asm volatile("" : "+v"(lane));  // keeps the per-lane table reads inside the streaming loop instead of pinning registers
-  const int blk = lane >> 2, j = lane & 3;
   const int U = mel_u_of<Mel>(p);
   const int sets = SED_SKIP(32) ? 0 : mel_sets_of<Mel>(p);
   int boff[kMaxMelSets];
@@ -251,7 +252,7 @@ __device__ __forceinline__ void mel_mfma_4frames(const FrontParams& p, const int
   static_for<0, kMaxMelSets>([&](auto Sf) {
     constexpr int s = decltype(Sf)::value;
     if (s < sets) {
-      const float* bp = prow0 + boff[s];
+      const float* bp = prow0 + (boff[s] & 0xffff);
       const float* ap = mela + ((size_t)s * (U + 1) * 64 + lane) * 4;
       v4 acc = v4{0.0f, 0.0f, 0.0f, 0.0f};
       for (int u0 = 0; u0 < U; u0 += kMelBurst) {
@@ -282,7 +283,7 @@ __device__ __forceinline__ void mel_mfma_4frames(const FrontParams& p, const int
           }
         });
       }
-      st4(part + (s * 16 + blk) * kPartStride + j * 4, acc);
+      st4(part + (boff[s] >> 16), acc);
     }
   });
   wave_phase_fence();
@@ -694,7 +695,10 @@ static void build_image(sed_plan* pl) {
   std::copy(sc.a.begin(), sc.a.end(), img.begin() + im.off_mela);
   int32_t* boff = reinterpret_cast<int32_t*>(img.data() + im.off_boff);
   for (int s = 0; s < kMaxMelSets; ++s)
-    for (int ln = 0; ln < 64; ++ln) boff[s * 64 + ln] = s < sc.sets ? (ln & 3) * G::PP + sc.base[s * 16 + (ln >> 2)] : 0;
+    for (int ln = 0; ln < 64; ++ln)  // low half: the lane's first power value; high half: where its partial sums go
+      boff[s * 64 + ln] = s < sc.sets ? ((ln & 3) * G::PP + sc.base[s * 16 + (ln >> 2)]) |
+                                            ((sc.slot[s * 16 + (ln >> 2)] * kPartStride + (ln & 3) * 4) << 16)
+                                      : 0;
   int32_t* gw = reinterpret_cast<int32_t*>(img.data() + im.off_gw);
   for (int ol = 0; ol < 128; ++ol) {  // gather word of output lane ol: lane 4*quad + frame sums the partial sums of its quad
     const int q = ol >> 2, jj = ol & 3;

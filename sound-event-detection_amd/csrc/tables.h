@@ -193,7 +193,8 @@ struct MelMfmaSchedule {
   int max_pos = 0;     // most positions any quad was cut into
   std::vector<float> a;         // [set][tau/4 + 1][lane = 4*block + i][4]: weight of bin base+4u+e for mel 4*quad+i; the last step of a set is all zero
   std::vector<int32_t> base;    // [set][block]: first bin the position reads (multiple of 4, base + tau <= row_pitch)
-  std::vector<int32_t> quadpos; // [quad]: first position | (number of positions << 16); a quad's positions are consecutive
+  std::vector<int32_t> slot;    // [set][block]: where the block's partial sums go (positions in quad order; unused blocks behind them)
+  std::vector<int32_t> quadpos; // [quad]: first slot | (number of positions << 16); a quad's slots are consecutive
 };
 
 inline MelMfmaSchedule schedule_mel_mfma(const std::vector<float>& melW, int F, int M, int row_pitch, int max_sets = 4) {
@@ -225,22 +226,49 @@ inline MelMfmaSchedule schedule_mel_mfma(const std::vector<float>& melW, int F, 
   const int P = 16 * sc.sets, U = sc.tau / 4;
   sc.a.assign((size_t)sc.sets * (U + 1) * 64 * 4, 0.0f);
   sc.base.assign(P, 0);
+  sc.slot.assign(P, 0);
+  // Positions in quad order (= the order of their partial-sum slots), then their places (set, block).  The 16 lanes the
+  // LDS serves together when the power values are fetched are 4 consecutive blocks x 4 frames, frame rows 16 banks
+  // apart, 4 banks per lane: they fall on distinct banks when the first bins of the 4 blocks differ mod 16 in their
+  // multiple of 4.  So the positions are dealt out to the groups of 4 blocks like cards, sorted by that residue: every
+  // group gets its even share of each residue (all four when the filterbank offers them).
+  struct Pos { int quad, seg_lo, seg_hi, base; };
+  std::vector<Pos> pos;
   std::vector<std::vector<int>> of_quad(NQ);
-  int p = 0;
   for (int q = 0; q < NQ; ++q) {
     const int nseg = std::max(1, (len[q] + sc.tau - 1) / sc.tau);
-    for (int g = 0; g < nseg; ++g, ++p) {
+    for (int g = 0; g < nseg; ++g) {
       const int seg_lo = lo[q] + g * sc.tau, seg_hi = std::min(lo[q] + len[q], seg_lo + sc.tau);  // bins owned
       const int base = std::max(0, std::min(seg_lo, row_pitch - sc.tau));                          // bins read
-      sc.base[p] = base;
-      of_quad[q].push_back(p);
-      const int set = p / 16, block = p % 16;
-      for (int t = 0; t < sc.tau; ++t) {
-        const int k = base + t;
-        if (k < seg_lo || k >= seg_hi || k >= F) continue;
-        for (int i = 0; i < 4 && 4 * q + i < M; ++i)
-          sc.a[(((size_t)set * (U + 1) + t / 4) * 64 + 4 * block + i) * 4 + t % 4] = melW[(size_t)k * M + 4 * q + i];
-      }
+      of_quad[q].push_back((int)pos.size());
+      pos.push_back(Pos{q, seg_lo, seg_hi, base});
+    }
+  }
+  std::vector<int> order(pos.size());
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return (pos[x].base / 4) % 4 < (pos[y].base / 4) % 4; });
+  const int n_groups = 4 * sc.sets;
+  std::vector<int> filled(n_groups, 0), place_of(pos.size(), 0);
+  std::vector<char> used(P, 0);
+  for (size_t i = 0; i < order.size(); ++i) {
+    const int grp = (int)(i % n_groups);
+    place_of[order[i]] = 4 * grp + filled[grp]++;
+    used[place_of[order[i]]] = 1;
+  }
+  int spare = (int)pos.size();  // unused places (all-zero weights) keep slots of their own behind the real ones
+  for (int pl = 0; pl < P; ++pl)
+    if (!used[pl]) sc.slot[pl] = spare++;
+  for (size_t p = 0; p < pos.size(); ++p) {
+    const int q = pos[p].quad, seg_lo = pos[p].seg_lo, seg_hi = pos[p].seg_hi, base = pos[p].base;
+    const int place = place_of[p];
+    sc.base[place] = base;
+    sc.slot[place] = (int)p;
+    const int set = place / 16, block = place % 16;
+    for (int t = 0; t < sc.tau; ++t) {
+      const int k = base + t;
+      if (k < seg_lo || k >= seg_hi || k >= F) continue;
+      for (int i = 0; i < 4 && 4 * q + i < M; ++i)
+        sc.a[(((size_t)set * (U + 1) + t / 4) * 64 + 4 * block + i) * 4 + t % 4] = melW[(size_t)k * M + 4 * q + i];
     }
   }
   for (const auto& v : of_quad) sc.max_pos = std::max(sc.max_pos, (int)v.size());
