@@ -115,7 +115,7 @@ void chunked(float* d) {
 
 // The balanced loop with span staging added: per round every wavefront also orders NB x 8 KB by LDS-DMA (into its own
 // span region, waited for at the top of the next round), from a buffer that streams through HBM / L2.
-template <int NV, int NR, int NW, int NB, int SPANS = 32, bool WAIT = true, int BYTES = 16>
+template <int NV, int NR, int NW, int NB, int SPANS = 32, bool WAIT = true, int MODE = 0>
 __global__ void __launch_bounds__(768) kd(const float* src, float* out, int iters) {
   extern __shared__ __align__(16) float lds[];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -131,14 +131,20 @@ __global__ void __launch_bounds__(768) kd(const float* src, float* out, int iter
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
       const float* gi = g + ((it * NB + nb) & (SPANS - 1)) * 1280;
+      v4 sp[8];
+      if (MODE == 0) {
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const auto* gs = (const __attribute__((address_space(1))) void*)(gi + 1024 * q);
-        auto* ld = (__attribute__((address_space(3))) void*)(X + 1024 * q);
-        __builtin_amdgcn_global_load_lds(gs, ld, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(gs, ld, 16, 1024, 0);
-        __builtin_amdgcn_global_load_lds(gs, ld, 16, 2048, 0);
-        __builtin_amdgcn_global_load_lds(gs, ld, 16, 3072, 0);
+        for (int q = 0; q < 2; ++q) {
+          const auto* gs = (const __attribute__((address_space(1))) void*)(gi + 1024 * q);
+          auto* ld = (__attribute__((address_space(3))) void*)(X + 1024 * q);
+          __builtin_amdgcn_global_load_lds(gs, ld, 16, 0, 0);
+          __builtin_amdgcn_global_load_lds(gs, ld, 16, 1024, 0);
+          __builtin_amdgcn_global_load_lds(gs, ld, 16, 2048, 0);
+          __builtin_amdgcn_global_load_lds(gs, ld, 16, 3072, 0);
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) sp[q] = *reinterpret_cast<const v4*>(gi + 256 * q);
       }
 #pragma unroll
       for (int i = 0; i < NV / NB / 4; ++i) {
@@ -155,17 +161,21 @@ __global__ void __launch_bounds__(768) kd(const float* src, float* out, int iter
                      : "v"(ya), "n"(0), "n"(1024), "n"(2048), "n"(3072) : "memory");
 #pragma unroll
       for (int i = 0; i < NW / NB; ++i) asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(ya), "v"(a), "n"(4096 + 8 * (i % 32)) : "memory");
+      if (MODE == 1) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) *reinterpret_cast<v4*>(X + 256 * q + 4 * lane) = sp[q];
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3)::"memory");
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   out[blockIdx.x * 768 + t] = a.x + a.y + d.x + d.y + e.x + f.y + r0.x + r1.y + r2.z + r3.w + X[lane];
 }
-template <int NV, int NR, int NW, int NB, int SPANS = 32, bool WAIT = true>
+template <int NV, int NR, int NW, int NB, int SPANS = 32, bool WAIT = true, int MODE = 0>
 double rund(const float* s, float* d) {
   const int iters = 2000;
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-  auto kern = kd<NV, NR, NW, NB, SPANS, WAIT>;
+  auto kern = kd<NV, NR, NW, NB, SPANS, WAIT, MODE>;
   (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipLaunchKernelGGL(kern, dim3(256), dim3(768), 12 * 3200 * 4, 0, s, d, iters);
   (void)hipEventRecord(e0);
@@ -203,6 +213,8 @@ int main() {
     printf("   ... 3 x 8 KB, every wavefront re-reading one span (L2 / L1 resident): %7.1f ns per round\n", rund<768, 96, 48, 3, 1>(src, d));
     printf("   ... 3 x 8 KB from HBM, never waited for (vmcnt only at the end):        %7.1f ns per round\n", rund<768, 96, 48, 3, 32, false>(src, d));
     printf("   ... 3 x 8 KB re-read, never waited for:                                  %7.1f ns per round\n", rund<768, 96, 48, 3, 1, false>(src, d));
+    printf("   ... 3 x 8 KB from HBM through registers (8 x global_load_dwordx4 early, 8 x ds_write_b128 late): %7.1f ns per round\n", rund<768, 96, 48, 3, 32, false, 1>(src, d));
+    printf("   ... 3 x 8 KB re-read through registers:                                                           %7.1f ns per round\n", rund<768, 96, 48, 3, 1, false, 1>(src, d));
     printf(" 768 pk_fma | 96 read_b128 + 48 write_b64 + 1 x 8 KB LDS-DMA per wavefront and round               : %7.1f ns per round\n", with1);
   }
   return 0;
