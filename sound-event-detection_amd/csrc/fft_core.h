@@ -196,6 +196,10 @@ struct LaneState {
   v2 q[G::R2];        // stage-2 FFT for k1 = R1 - l   (lane 0: k1 = R1/2)
 };
 
+#if defined(__HIP_DEVICE_COMPILE__)
+SED_HD unsigned lds_addr(const float* p) { return (unsigned)(size_t)p; }  // low half of a generic LDS address = LDS offset
+#endif
+
 // Sample sources for stage 1: fp32 PCM (LDS or global memory) and int16 PCM (divided by `div`, as the
 // int16 -> fp32 conversion of the reference does).  Offsets are in samples from the frame's first sample and are
 // multiples of the access width.
@@ -228,7 +232,35 @@ struct SrcI16 {
 // tw1_slot().
 // Issue order: all samples and the first half of the window, then (as the products of the first half are formed)
 // the second half of the window and the twiddles, so that every table value is in flight long before it is used.
-template <class G, class Src>
+// Sample fetch of stage 1 from a span staged with a skew: the samples of hop h (HOP floats each) start at float
+// h * (HOP + SKEW) of the span, so that the two frames whose lanes the LDS serves together start 32 banks apart when the
+// hop itself is a multiple of 64 floats.  HOP is a multiple of 2 * R2, so a lane's pair never straddles two hops and
+// every offset is an immediate.  Hand-written 8-byte reads (the compiler would fuse pairs of them into the slower
+// ds_read2_b64); it does not count them, so the first use of a sample must come after a wait for a younger LDS read
+// (lane_stage1 issues the window reads after them and multiplies every sample by a window value first).
+template <class G, int HOP, int SKEW>
+SED_HD void lane_load_samples_skewed(LaneState<G>& st, const float* frame, int l) {
+  static_assert(G::A == 1 && HOP % (2 * G::R2) == 0, "one stage-1 FFT per lane, hops of whole lane rows");
+  constexpr int LOG1 = ilog2(G::R1);
+#if defined(__HIP_DEVICE_COMPILE__)
+  const unsigned fa = lds_addr(frame + 2 * l);
+#endif
+  static_for<0, G::R1>([&](auto N1) {
+    constexpr int n1 = decltype(N1)::value;
+    constexpr int off = 2 * G::R2 * n1 + SKEW * ((2 * G::R2 * n1) / HOP);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned addr = fa;
+    v2 val;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(val) : "v"(addr), "n"(4 * off) : "memory");
+    st.y[0][bitrev(n1, LOG1)] = val;
+#else
+    st.y[0][bitrev(n1, LOG1)] = ld2(frame + 2 * l + off);
+#endif
+  });
+}
+
+// LOADED: st.y[0] already holds the samples in bit-reversed order (lane_load_samples_skewed), src is not read.
+template <class G, class Src, bool LOADED = false>
 SED_HD void lane_stage1(LaneState<G>& st, const Src src, const float* win, const float* tw1, int l) {
   constexpr int LOG1 = ilog2(G::R1), H = G::R1 / 2;
   if constexpr (G::A == 1) {
@@ -248,10 +280,12 @@ SED_HD void lane_stage1(LaneState<G>& st, const Src src, const float* win, const
         st.y[0][bitrev(n1 + 1, LOG1)] *= w[q][i].zw;
       });
     };
-    static_for<0, G::R1>([&](auto N1) {
-      constexpr int n1 = decltype(N1)::value;
-      st.y[0][bitrev(n1, LOG1)] = SED_SKIP(4) ? v2{(float)(l + n1), 1.0f} : src.load2(2 * G::R2 * n1 + 2 * l);
-    });
+    if constexpr (!LOADED) {
+      static_for<0, G::R1>([&](auto N1) {
+        constexpr int n1 = decltype(N1)::value;
+        st.y[0][bitrev(n1, LOG1)] = SED_SKIP(4) ? v2{(float)(l + n1), 1.0f} : src.load2(2 * G::R2 * n1 + 2 * l);
+      });
+    }
     issue_window(std::integral_constant<int, 0>{});
     issue_window(std::integral_constant<int, 1>{});
     SED_SCHED_FENCE();
@@ -366,10 +400,6 @@ SED_HD void lane_stage1_conditioned(LaneState<G>& st, const float* frame, const 
 // CU, ds_read_b64 0.95 ns against 3.4 ns for the ds_read2_b64 the compiler would fuse two of them into, and
 // ds_write_b64 2.6 ns against 5.8 ns for a ds_write_b128.  The compiler does not count hand-written LDS reads, so
 // lane_xwait() must come between the last read and the first use of st.p / st.q.
-#if defined(__HIP_DEVICE_COMPILE__)
-SED_HD unsigned lds_addr(const float* p) { return (unsigned)(size_t)p; }  // low half of a generic LDS address = LDS offset
-#endif
-
 template <class G, int PH>
 SED_HD void lane_xwrite(const LaneState<G>& st, float* xfr, int l) {
   static_for<0, G::A>([&](auto Af) {

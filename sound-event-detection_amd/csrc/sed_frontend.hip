@@ -133,13 +133,14 @@ __device__ __forceinline__ float load_padded(const T* src, int64_t s, int64_t L,
 // its address arithmetic is not hoisted into the streaming loop.
 __device__ __attribute__((noinline)) void stage_span_edges(const void* pcm, int pcm_kind, float div, int64_t L,
                                                            int pad_mode, int64_t clip_off, float* dst, int64_t s0,
-                                                           int count, int lane) {
+                                                           int count, int lane, int hop, int skew) {
+  // sample i of the span goes to float i + skew * (i / hop) (skew 0: the plain layout)
   if (pcm_kind == SED_PCM_F32) {
     const float* src = (const float*)pcm + clip_off;
-    for (int i = lane; i < count; i += 64) dst[i] = load_padded<float>(src, s0 + i, L, pad_mode, 1.0f);
+    for (int i = lane; i < count; i += 64) dst[i + (skew ? skew * (i / hop) : 0)] = load_padded<float>(src, s0 + i, L, pad_mode, 1.0f);
   } else {
     const int16_t* src = (const int16_t*)pcm + clip_off;
-    for (int i = lane; i < count; i += 64) dst[i] = load_padded<int16_t>(src, s0 + i, L, pad_mode, div);
+    for (int i = lane; i < count; i += 64) dst[i + (skew ? skew * (i / hop) : 0)] = load_padded<int16_t>(src, s0 + i, L, pad_mode, div);
   }
 }
 
@@ -150,13 +151,16 @@ struct __attribute__((packed, aligned(2))) i16x4_u { short x, y, z, w; };
 // One wavefront copies `count` samples (multiple of 4) of clip b, starting at padded-clip sample s0, to LDS.
 // The fast path issues its loads in batches of 8 x 4 samples per lane before the first LDS store, with clamped
 // (never predicated) addresses: a load under a divergent branch would be waited for on its own.
-template <bool I16>
+// HOP / SKEW: the skewed layout (groups of 4 samples never straddle a hop: both are multiples of 4).
+template <bool I16, int HOP = 0, int SKEW = 0>
 __device__ __forceinline__ void stage_span(const FrontParams& p, float* dst, int64_t b, int64_t s0, int count, int lane) {
+  auto at = [](int i) { if constexpr (SKEW > 0) return i + SKEW * (i / HOP); else return i; };
   // (int16 plans whose divisor failed the three-instruction check take the out-of-line path with the IEEE division)
   bool fast = s0 >= 0 && s0 + count <= p.L;
   if constexpr (I16) fast = fast && (p.pcm_kind & kPcmDiv3);
   if (!fast) {
-    stage_span_edges(p.pcm, p.pcm_kind & ~kPcmDiv3, p.pcm_div, p.L, p.pad_mode, b * p.pcm_stride, dst, s0, count, lane);
+    stage_span_edges(p.pcm, p.pcm_kind & ~kPcmDiv3, p.pcm_div, p.L, p.pad_mode, b * p.pcm_stride, dst, s0, count, lane,
+                     SKEW > 0 ? HOP : 1, SKEW);
   } else if constexpr (!I16) {
     const float* src = (const float*)p.pcm + b * p.pcm_stride + s0;
     for (int base = 0; base < count; base += 8 * 256) {
@@ -166,7 +170,7 @@ __device__ __forceinline__ void stage_span(const FrontParams& p, float* dst, int
       });
       static_for<0, 8>([&](auto Kf) {
         const f32x4_u w = v[decltype(Kf)::value];
-        st4(dst + min(base + 256 * decltype(Kf)::value + 4 * lane, count - 4), v4{w.x, w.y, w.z, w.w});
+        st4(dst + at(min(base + 256 * decltype(Kf)::value + 4 * lane, count - 4)), v4{w.x, w.y, w.z, w.w});
       });
     }
   } else {
@@ -179,7 +183,7 @@ __device__ __forceinline__ void stage_span(const FrontParams& p, float* dst, int
       });
       static_for<0, 8>([&](auto Kf) {
         const i16x4_u w = v[decltype(Kf)::value];
-        st4(dst + min(base + 256 * decltype(Kf)::value + 4 * lane, count - 4),
+        st4(dst + at(min(base + 256 * decltype(Kf)::value + 4 * lane, count - 4)),
             v4{pcm16_to_f32((float)w.x, p.pcm_div, rcp), pcm16_to_f32((float)w.y, p.pcm_div, rcp),
                pcm16_to_f32((float)w.z, p.pcm_div, rcp), pcm16_to_f32((float)w.w, p.pcm_div, rcp)});
       });
@@ -214,18 +218,69 @@ __device__ __forceinline__ void stage_span_dma(const FrontParams& p, float* dst,
   }
 }
 
+// The same for the skewed layout: hop h of the span (HOP samples; the last one NFFT - ... samples short) lands at float
+// h * (HOP + SKEW), as 16-byte pieces of 256 samples and 4-byte pieces of 64.  The instruction offset moves source and
+// destination together and the LDS base (M0) takes the rest, so two per-lane addresses serve up to four hops.
+template <class G, int HOP, int SKEW>
+__device__ __forceinline__ void stage_span_dma_skewed(const FrontParams& p, float* dst, int64_t b, int64_t s0, int lane) {
+  constexpr int SPAN = (G::FPW - 1) * HOP + G::NFFT;
+  constexpr int HOPS = (SPAN + HOP - 1) / HOP;
+  static_assert(HOP % 64 == 0 && SPAN % 64 == 0 && HOP * 4 * 3 + 4096 > 0, "whole 64-sample pieces");
+  const float* src = (const float*)p.pcm + b * p.pcm_stride + s0;
+  static_for<0, (HOPS + 2) / 3>([&](auto Tf) {
+    constexpr int h0 = 3 * decltype(Tf)::value;  // three hops per pair of per-lane addresses: offsets stay below 4096 bytes
+    const float* s16 = src + h0 * HOP + 4 * lane;
+    const float* s4 = src + h0 * HOP + lane;
+    static_for<0, 3>([&](auto Hf) {
+      constexpr int h = h0 + decltype(Hf)::value;
+      if constexpr (h < HOPS) {
+        constexpr int n = (h + 1) * HOP <= SPAN ? HOP : SPAN - h * HOP;  // samples of this hop that the span holds
+        constexpr int N16 = n / 256, N4 = (n % 256) / 64;
+        constexpr int goff = (h - h0) * HOP;  // source offset from the per-lane address, in floats
+        float* d = dst + h * (HOP + SKEW) - goff;  // so that d + goff is where the hop goes
+        static_for<0, N16>([&](auto Jf) {
+          constexpr int off = 4 * (goff + 256 * decltype(Jf)::value);
+          static_assert(off < 4096, "13-bit instruction offset");
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s16,
+                                           (__attribute__((address_space(3))) void*)d, 16, off, 0);
+        });
+        static_for<0, N4>([&](auto Jf) {
+          constexpr int off = 4 * (goff + 256 * N16 + 64 * decltype(Jf)::value);
+          static_assert(off < 4096, "13-bit instruction offset");
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s4,
+                                           (__attribute__((address_space(3))) void*)d, 4, off, 0);
+        });
+      }
+    });
+  });
+}
+
 // Shape of a plan's mel schedule.  The shapes of the reference's own flavours are compiled in, which turns the
 // loops over accumulator sets, steps and positions into straight-line code; any other filterbank runs the same code with
 // the shape read from the launch parameters.
-template <int SETS_, int U_, int MAXPOS_, int ROUNDS_>
+template <int SETS_, int U_, int MAXPOS_, int ROUNDS_, int HOP_ = 0>
 struct MelStatic {
   static constexpr bool kStatic = true;
   static constexpr int SETS = SETS_, U = U_, MAXPOS = MAXPOS_, ROUNDS = ROUNDS_;
+  static constexpr int HOP = HOP_;  // the flavour's hop when it is compiled in too (0: read from the launch parameters)
 };
 struct MelDynamic {
   static constexpr bool kStatic = false;
-  static constexpr int SETS = 0, U = 0, MAXPOS = 0, ROUNDS = 0;
+  static constexpr int SETS = 0, U = 0, MAXPOS = 0, ROUNDS = 0, HOP = 0;
 };
+
+// Skew of the staged span, in floats per hop.  With 16 lanes per frame the LDS serves the sample reads of two frames
+// together, each frame's lanes covering 32 consecutive banks: when the hop is a multiple of 64 floats both frames sit
+// on the same 32 banks and every read takes two passes (measured 1.71 against 0.94 ns per instruction and CU).  The
+// span is then staged hop by hop, each hop 32 floats further than the samples before it, which puts the second frame
+// on the other 32 banks.  Needs the hop at compile time (the reads keep immediate offsets) and whole 64-float DMA
+// pieces per hop.
+template <class G, class Mel, bool PRE, bool SPEC_OUT>
+constexpr int span_skew() {
+  return (Mel::HOP > 0 && !PRE && !SPEC_OUT && G::A == 1 && G::LPF == 16 && Mel::HOP % 64 == 0) ? 32 : 0;
+}
+// floats of LDS a skewed span of `span` samples takes
+constexpr int skewed_floats(int span, int hop, int skew) { return (span + skew * ((span - 1) / hop) + 3) & ~3; }
 template <class Mel> __device__ __forceinline__ int mel_sets_of(const FrontParams& p) { if constexpr (Mel::kStatic) return Mel::SETS; else return p.mel_sets; }
 template <class Mel> __device__ __forceinline__ int mel_u_of(const FrontParams& p) { if constexpr (Mel::kStatic) return Mel::U; else return p.mel_u; }
 template <class Mel> __device__ __forceinline__ int mel_maxpos_of(const FrontParams& p) { if constexpr (Mel::kStatic) return Mel::MAXPOS; else return p.mel_maxpos; }
@@ -373,6 +428,9 @@ stft_mel_kernel(const FrontParams p) {
   const int lane = tid & 63;
   const int fi = lane / G::LPF, l = lane % G::LPF;
   const int wg_waves = NT >> 6;
+  constexpr int SKEW = span_skew<G, Mel, PRE, SPEC_OUT>();
+  // samples from the start of the span that an LDS-DMA transfer of it reads
+  const int dma_reach = SKEW > 0 ? (G::FPW - 1) * Mel::HOP + G::NFFT : 256 * p.span_blocks;
 
   float* winL = smem;
   float* tw1L = smem + p.im.off_tw1;
@@ -419,10 +477,11 @@ stft_mel_kernel(const FrontParams p) {
       const int64_t s0 = (int64_t)f0 * p.hop - p.pad_left;
       LaneState<G> st;
       if (!staged) {
-        if (!I16 && p.dma && s0 >= 0 && s0 + 256 * p.span_blocks <= p.L) {
-          if (!SED_SKIP(1)) stage_span_dma(p, X, b, s0, lane);
+        if (!I16 && p.dma && s0 >= 0 && s0 + dma_reach <= p.L) {
+          if constexpr (SKEW > 0) stage_span_dma_skewed<G, Mel::HOP, SKEW>(p, X, b, s0, lane);
+          else if (!SED_SKIP(1)) stage_span_dma(p, X, b, s0, lane);
         } else {
-          stage_span<I16>(p, X, b, s0, p.span, lane);
+          stage_span<I16, Mel::HOP, SKEW>(p, X, b, s0, p.span, lane);
         }
       }
       SED_STAMP(0)
@@ -451,7 +510,12 @@ stft_mel_kernel(const FrontParams p) {
         }
         lane_stage1_conditioned<G>(st, X + fi * p.hop, winL, tw1L, l, mean, p.preemph);
       } else {
-        lane_stage1<G>(st, SrcF32{X + fi * p.hop}, winL, tw1L, l);
+        if constexpr (SKEW > 0) {
+          lane_load_samples_skewed<G, Mel::HOP, SKEW>(st, X + fi * (Mel::HOP + SKEW), l);
+          lane_stage1<G, SrcF32, true>(st, SrcF32{nullptr}, winL, tw1L, l);
+        } else {
+          lane_stage1<G>(st, SrcF32{X + fi * p.hop}, winL, tw1L, l);
+        }
       }
       wave_phase_fence();
       SED_STAMP(2)
@@ -495,8 +559,9 @@ stft_mel_kernel(const FrontParams p) {
           if constexpr (g == kGroups - 1) {
             // the power rows are consumed: the next group's span may land on them while the gather runs
             const int64_t s1 = (int64_t)nf0 * p.hop - p.pad_left;
-            if (!I16 && p.early && more && s1 >= 0 && s1 + 256 * p.span_blocks <= p.L && !SED_SKIP(1)) {
-              stage_span_dma(p, X, nb, s1, lane);
+            if (!I16 && p.early && more && s1 >= 0 && s1 + dma_reach <= p.L && !SED_SKIP(1)) {
+              if constexpr (SKEW > 0) stage_span_dma_skewed<G, Mel::HOP, SKEW>(p, X, nb, s1, lane);
+              else stage_span_dma(p, X, nb, s1, lane);
               staged = true;
             }
           }
@@ -917,11 +982,14 @@ static int launch_front_shape(const sed_plan* pl, FrontParams p, int64_t B, hipS
   p.span = round4((G::FPW - 1) * p.hop + G::NFFT);
   p.span_blocks = (p.span + 255) / 256;
   if (p.span_blocks > kMaxSpanBlocks) return SED_ERR_BAD_ARG;
-  p.part_off = G::FPW * G::PP;
-  p.early = p.dma && !SPEC_OUT && 256 * p.span_blocks <= p.part_off;  // the span may land while the partial sums are in use
+  constexpr int SKEW = span_skew<G, Mel, PRE, SPEC_OUT>();
+  // floats of the region an early span transfer writes: whole 1 KB blocks, or the skewed span exactly
+  const int span_floats = SKEW > 0 ? skewed_floats(p.span, Mel::HOP, SKEW) : 256 * p.span_blocks;
+  p.part_off = std::max(G::FPW * G::PP, SKEW > 0 ? span_floats : 0);  // (a skewed span may reach past the power rows)
+  p.early = p.dma && !SPEC_OUT && span_floats <= p.part_off;  // the span may land while the partial sums are in use
   const int part_floats = SPEC_OUT ? 0 : p.mel_sets * 16 * kPartStride;
   p.pre_off = 256 * p.span_blocks;  // behind the staged span: FPW frames x LPF partial sums (Kaldi DC removal)
-  p.wave_floats = round64(std::max(std::max(256 * p.span_blocks + (PRE ? 64 : 0), G::FPW * G::XFR), p.part_off + part_floats));
+  p.wave_floats = round64(std::max(std::max(span_floats + (PRE ? 64 : 0), G::FPW * G::XFR), p.part_off + part_floats));
   // shared tables (the plan's image), then the work-queue head, then the wave regions
   p.im = pl->im;
   p.image = pl->d_image;
@@ -1040,6 +1108,7 @@ static int launch_front(const sed_plan* pl, const FrontParams& p, int64_t B, hip
       return p.mel_sets == sets && p.mel_u == u && p.mel_maxpos == maxpos && two == rounds2;
     };
     if constexpr (G::NFFT == 1024 && !MAG && !PRE) {  // HTS-AT: Slaney 64 mel, 50..14000 Hz at 32 kHz
+      if (is(2, 6, 5, false) && p.hop == 320) return launch_front_shape<G, MAG, SPEC_OUT, PRE, MelStatic<2, 6, 5, 1, 320>>(pl, p, B, stream);
       if (is(2, 6, 5, false)) return launch_front_shape<G, MAG, SPEC_OUT, PRE, MelStatic<2, 6, 5, 1>>(pl, p, B, stream);
     }
     if constexpr (G::NFFT == 512 && MAG && !PRE) {  // YAMNet: HTK 64 mel, 125..7500 Hz at 16 kHz
