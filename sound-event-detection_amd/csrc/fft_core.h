@@ -58,6 +58,17 @@ SED_HD v2 ld2(const cplx* p) { return *reinterpret_cast<const v2*>(p); }
 SED_HD v4 ld4(const float* p) { return *reinterpret_cast<const v4*>(p); }
 SED_HD void st4(float* p, v4 v) { *reinterpret_cast<v4*>(p) = v; }
 
+// Square root of a power value for the magnitude spectra.  On the device: the v_sqrt_f32 instruction itself (1 ulp;
+// inputs below 2^-126 count as zero), one instruction where the IEEE-exact sqrtf expands to about ten.  The magnitudes
+// only feed a mel sum and a logarithm with an additive offset (1e-3 or 1e-9), or a spectrogram compared to 2e-6.
+SED_HD float fast_sqrt(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_sqrtf(x);
+#else
+  return std::sqrt(x);
+#endif
+}
+
 SED_HD v2 pk_fma(v2 a, v2 b, v2 c) { return __builtin_elementwise_fma(a, b, c); }
 SED_HD v2 swp(v2 a) { return __builtin_shufflevector(a, a, 1, 0); }
 SED_HD v2 lo2(v2 a) { return __builtin_shufflevector(a, a, 0, 0); }
@@ -523,7 +534,7 @@ SED_HD void lane_stage2_power(LaneState<G>& st, float* pw, const float* tw2, int
     const v2 re = pk_fma(lo2(tt), k, lo2(e)); // (Re X[k], Re X[NC-k])
     const v2 im = pk_fma(hi2(tt), k, hi2(e)); // (Im X[k], -Im X[NC-k])
     v2 pp = pk_fma(im, im, re * re);
-    if constexpr (MAGNITUDE) pp = v2{__builtin_sqrtf(pp.x), __builtin_sqrtf(pp.y)};
+    if constexpr (MAGNITUDE) pp = v2{fast_sqrt(pp.x), fast_sqrt(pp.y)};
     float* lo = qslot ? lo_q : lo_p;
     float* hi = qslot ? hi_q : hi_p;
     if ((t != G::R2 / 2 + 1 || l0) && !(SED_SKIP(16) && pp.x != 12345.0f)) {
