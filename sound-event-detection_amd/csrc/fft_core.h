@@ -346,15 +346,29 @@ SED_HD void lane_stage1(LaneState<G>& st, const Src src, const float* win, const
 
 // Kaldi framing (torchaudio.compliance.kaldi._get_window): sum of the lane's samples among the first win_length of
 // the frame (the mean over win_length samples is removed before pre-emphasis and windowing).
-template <class G>
+// VEC: the frame starts on a multiple of 2 * A floats, so a lane's 2 * A consecutive samples come in one 8- or 16-byte
+// read (same values, same summation order).  Besides the instruction count this removes the bank conflicts of the
+// 4-byte reads, whose 64 lanes are served together: with 8 frames of 8 lanes in a wavefront and a hop of 160 floats,
+// every other frame sits on the same banks.
+template <class G, bool VEC = false>
 SED_HD float lane_frame_sum(const float* frame, int l, int win_length) {
   float sum = 0.0f;
   static_for<0, G::R1>([&](auto N1) {
     constexpr int n1 = decltype(N1)::value;
     const int base = 2 * G::R2 * n1 + 2 * G::A * l;
+    float x[2 * G::A];
+    if constexpr (VEC && G::A == 2) {
+      const v4 v = ld4(frame + base);
+      x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+    } else if constexpr (VEC) {
+      const v2 v = ld2(frame + base);
+      x[0] = v.x; x[1] = v.y;
+    } else {
+      static_for<0, 2 * G::A>([&](auto Ef) { x[decltype(Ef)::value] = frame[base + decltype(Ef)::value]; });
+    }
     static_for<0, 2 * G::A>([&](auto Ef) {
       constexpr int e = decltype(Ef)::value;
-      sum += (base + e < win_length) ? frame[base + e] : 0.0f;
+      sum += (base + e < win_length) ? x[e] : 0.0f;
     });
   });
   return sum;
@@ -363,7 +377,7 @@ SED_HD float lane_frame_sum(const float* frame, int l, int win_length) {
 // Stage 1 with per-frame conditioning: y[n] = (x[n] - mean) - c (x[n-1] - mean), x[-1] := x[0], then window, FFT(s)
 // and inter-stage twiddle as in lane_stage1.  frame: the frame's samples in natural order (frame[-1] must be
 // readable; its value is not used).
-template <class G>
+template <class G, bool VEC = false>
 SED_HD void lane_stage1_conditioned(LaneState<G>& st, const float* frame, const float* win, const float* tw1, int l,
                                     float mean, float c) {
   constexpr int LOG1 = ilog2(G::R1);
@@ -373,7 +387,15 @@ SED_HD void lane_stage1_conditioned(LaneState<G>& st, const float* frame, const 
     const int base = 2 * G::R2 * n1 + 2 * G::A * l;
     float x[2 * G::A + 1];
     x[0] = frame[base == 0 ? 0 : base - 1];
-    static_for<0, 2 * G::A>([&](auto Ef) { x[decltype(Ef)::value + 1] = frame[base + decltype(Ef)::value]; });
+    if constexpr (VEC && G::A == 2) {
+      const v4 v = ld4(frame + base);
+      x[1] = v.x; x[2] = v.y; x[3] = v.z; x[4] = v.w;
+    } else if constexpr (VEC) {
+      const v2 v = ld2(frame + base);
+      x[1] = v.x; x[2] = v.y;
+    } else {
+      static_for<0, 2 * G::A>([&](auto Ef) { x[decltype(Ef)::value + 1] = frame[base + decltype(Ef)::value]; });
+    }
     float y[2 * G::A];
     static_for<0, 2 * G::A>([&](auto Ef) {
       constexpr int e = decltype(Ef)::value;

@@ -501,14 +501,18 @@ stft_mel_kernel(const FrontParams p) {
         // Kaldi framing: the lanes of a frame pool their partial sums through LDS (fixed summation order), then
         // every lane conditions its own samples with the frame mean.
         float* pool = X + p.pre_off + fi * G::LPF;
-        pool[l] = lane_frame_sum<G>(X + fi * p.hop, l, p.win_length);
+        // wave-uniform: frames start on whole 8- / 16-byte units (n_fft 2048 keeps the one path its registers hold)
+        const bool vec = G::NFFT < 2048 && p.hop % (2 * G::A) == 0;
+        pool[l] = vec ? lane_frame_sum<G, true>(X + fi * p.hop, l, p.win_length)
+                      : lane_frame_sum<G, false>(X + fi * p.hop, l, p.win_length);
         wave_phase_fence();
         float mean = 0.0f;
         if (p.remove_dc) {
           for (int j = 0; j < G::LPF; ++j) mean += pool[j];
           mean *= p.inv_win_length;
         }
-        lane_stage1_conditioned<G>(st, X + fi * p.hop, winL, tw1L, l, mean, p.preemph);
+        if (vec) lane_stage1_conditioned<G, true>(st, X + fi * p.hop, winL, tw1L, l, mean, p.preemph);
+        else lane_stage1_conditioned<G, false>(st, X + fi * p.hop, winL, tw1L, l, mean, p.preemph);
       } else {
         if constexpr (SKEW > 0) {
           lane_load_samples_skewed<G, Mel::HOP, SKEW>(st, X + fi * (Mel::HOP + SKEW), l);
