@@ -366,10 +366,17 @@ SED_HD float lane_frame_sum(const float* frame, int l, int win_length) {
     } else {
       static_for<0, 2 * G::A>([&](auto Ef) { x[decltype(Ef)::value] = frame[base + decltype(Ef)::value]; });
     }
-    static_for<0, 2 * G::A>([&](auto Ef) {
-      constexpr int e = decltype(Ef)::value;
-      sum += (base + e < win_length) ? x[e] : 0.0f;
-    });
+    // rows of 2 * R2 samples wholly inside the window need no test, rows wholly outside add nothing (adding +0 to a
+    // sum that started from +0 leaves its bits alone): only the row the window ends in is predicated, and the tests on
+    // the row are wave-uniform
+    if (2 * G::R2 * (n1 + 1) <= win_length) {
+      static_for<0, 2 * G::A>([&](auto Ef) { sum += x[decltype(Ef)::value]; });
+    } else if (2 * G::R2 * n1 < win_length) {
+      static_for<0, 2 * G::A>([&](auto Ef) {
+        constexpr int e = decltype(Ef)::value;
+        sum += (base + e < win_length) ? x[e] : 0.0f;
+      });
+    }
   });
   return sum;
 }

@@ -503,8 +503,9 @@ stft_mel_kernel(const FrontParams p) {
         float* pool = X + p.pre_off + fi * G::LPF;
         // wave-uniform: frames start on whole 8- / 16-byte units (n_fft 2048 keeps the one path its registers hold)
         const bool vec = G::NFFT < 2048 && p.hop % (2 * G::A) == 0;
-        pool[l] = vec ? lane_frame_sum<G, true>(X + fi * p.hop, l, p.win_length)
-                      : lane_frame_sum<G, false>(X + fi * p.hop, l, p.win_length);
+        int wl = p.win_length;
+        asm volatile("" : "+s"(wl));  // the row tests stay scalar compares inside the loop instead of hoisted, spilled masks
+        pool[l] = vec ? lane_frame_sum<G, true>(X + fi * p.hop, l, wl) : lane_frame_sum<G, false>(X + fi * p.hop, l, wl);
         wave_phase_fence();
         float mean = 0.0f;
         if (p.remove_dc) {
