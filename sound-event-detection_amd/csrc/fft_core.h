@@ -161,12 +161,16 @@ struct Geo {
   static constexpr int FPI = WAVES * FPW;   // frames per workgroup iteration
   // Exchange rows: pitch RP and floats per frame XFR.  The LDS serves an 8-byte access 32 lanes at a time, i.e. 32 / LPF
   // frames together; the pads are picked (by enumerating every write and read instruction of the exchange) so that
-  // those lanes fall on distinct banks: none of the accesses of Geo<32,16,16> conflict; in the other two geometries
-  // the writes are conflict free and the reads 2-way.  (With pitch R1 + 4 and a 32-float frame pad the writes of two
-  // frames met on the same banks: 64 % of the kernel's bank-conflict cycles.)
-  static constexpr int RP = R1 + (LPF == 16 ? (R2 == 16 ? 6 : 2) : 4);
-  static constexpr int XFR = R2 * RP + (LPF == 16 ? (R2 == 16 ? 0 : 2) : 10);
+  // those lanes fall on distinct banks: no access of any of the three geometries conflicts.  (With pitch R1 + 4 and a
+  // 32-float frame pad the writes of two frames met on the same banks: 64 % of the kernel's bank-conflict cycles.)
+  // A lane with two stage-1 FFTs (n2 = 2l and 2l + 1) keeps them LPF rows apart, see xrow(): with its two rows
+  // adjacent, the lanes of a frame would be 2 * RP floats apart, a multiple of 4, and either the writes or the reads
+  // of the frames served together would share banks whatever the pitch.
+  static constexpr int RP = R1 + (LPF == 16 ? (R2 == 16 ? 6 : 2) : 2);
+  static constexpr int XFR = R2 * RP + (LPF == 16 ? (R2 == 16 ? 0 : 32) : 16);
   static_assert(RP % 2 == 0 && XFR % 2 == 0 && RP >= R1, "8-byte accesses, R1/2 complex values per row and phase");
+  // row of the frame's exchange region that holds the stage-1 results of n2
+  static constexpr int xrow(int n2) { return A == 1 ? n2 : n2 / A + LPF * (n2 % A); }
   static constexpr int PP = NC + 16;        // power-row pitch in floats (16 mod 64: the 4 frames of a wave tile the banks)
   static constexpr int SLOTS = R2 + 1;      // split slots per lane (one of them stores from lane 0 only)
   // Lane-major table layouts: the values one lane reads are contiguous, so that it fetches two of them per 16-byte
@@ -444,7 +448,7 @@ template <class G, int PH>
 SED_HD void lane_xwrite(const LaneState<G>& st, float* xfr, int l) {
   static_for<0, G::A>([&](auto Af) {
     constexpr int a = decltype(Af)::value;
-    float* row = xfr + (G::A * l + a) * G::RP;
+    float* row = xfr + (l + G::LPF * a) * G::RP;  // = xrow(A * l + a)
 #if defined(__HIP_DEVICE_COMPILE__)
     const unsigned ra = lds_addr(row);
     static_for<0, G::R1 / 2>([&](auto Q) {
@@ -482,12 +486,12 @@ SED_HD void lane_xread(LaneState<G>& st, const float* xfr, int l) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const unsigned addr = ca;
     v2 val;
-    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(val) : "v"(addr), "n"(4 * n2 * G::RP) : "memory");
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(val) : "v"(addr), "n"(4 * G::xrow(n2) * G::RP) : "memory");
     if constexpr (PH == 0) st.p[pos] = val;
     else st.q[pos] = val;
 #else
-    if constexpr (PH == 0) st.p[pos] = ld2(col + n2 * G::RP);
-    else st.q[pos] = ld2(col + n2 * G::RP);
+    if constexpr (PH == 0) st.p[pos] = ld2(col + G::xrow(n2) * G::RP);
+    else st.q[pos] = ld2(col + G::xrow(n2) * G::RP);
 #endif
   });
 }
