@@ -472,6 +472,7 @@ stft_mel_kernel(const FrontParams p) {
       ++tl_iters;
 #endif
       // take the next group now; the answer is needed when its span is ordered, half an iteration from here
+      SED_P(0);
       int taken = 0;
       if (lane == 0) taken = atomicAdd(qhead, 1);
       const int64_t s0 = (int64_t)f0 * p.hop - p.pad_left;
@@ -497,6 +498,7 @@ stft_mel_kernel(const FrontParams p) {
           });
         }
       }
+      SED_P(1);
       if constexpr (PRE) {
         // Kaldi framing: the lanes of a frame pool their partial sums through LDS (fixed summation order), then
         // every lane conditions its own samples with the frame mean.
@@ -526,6 +528,7 @@ stft_mel_kernel(const FrontParams p) {
       SED_STAMP(2)
       float* xfr = X + fi * G::XFR;
       if (!SED_SKIP(8)) {
+        SED_P(3);
         lane_xwrite<G, 0>(st, xfr, l);
         wave_phase_fence();
         lane_xread<G, 0>(st, xfr, l);
@@ -540,6 +543,7 @@ stft_mel_kernel(const FrontParams p) {
       }
       SED_STAMP(3)
       float* pw = X + fi * G::PP;
+      SED_P(4);
       lane_stage2_power<G, MAG>(st, pw, tw2L, l);
       for (int k = G::NBINS + l; k < G::PP; k += G::LPF) pw[k] = 0.0f;  // row padding read (with zero weight) by the mel stage
       wave_phase_fence();
@@ -559,8 +563,10 @@ stft_mel_kernel(const FrontParams p) {
         float* part = X + p.part_off;
         static_for<0, kGroups>([&](auto Gf) {
           constexpr int g = decltype(Gf)::value;
+          SED_P(5);
           mel_mfma_4frames<Mel>(p, boffL, X + 4 * g * G::PP, melaL, part, lane);
           SED_STAMP(5)
+          SED_P(6);
           if constexpr (g == kGroups - 1) {
             // the power rows are consumed: the next group's span may land on them while the gather runs
             const int64_t s1 = (int64_t)nf0 * p.hop - p.pad_left;
