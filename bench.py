@@ -17,6 +17,7 @@ Rank 0 prints one JSON line.
 process, before this process touches the GPU) and relays rank 0's line.
 """
 import argparse
+import contextlib
 import json
 import os
 import socket
@@ -62,6 +63,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
                     "rehearse the multi-rank control flow on a box with one GPU, together with --one-device)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--decode-stream", choices=["side", "same"], default="same",
+                    help="side: the detector decode of a step runs on a second HIP stream beside the front-end kernel")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be at least 1")
@@ -114,6 +117,7 @@ def main():
 
     k_events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     pending = []
+    side = torch.cuda.Stream(device=dev) if args.decode_stream == "side" else None
 
     def step(i=None):
         if i is not None:
@@ -123,8 +127,9 @@ def main():
             k_events[i][1].record()
         # decode -> records -> all-gather: the same function tests/test_gpu_sharding.py checks against the oracle
         # (the gloo rehearsal gathers host copies: gloo's device-tensor path stalls after a few async gathers)
-        out, work = sed_amd.sharding.decode_and_exchange(det, table, 0.6, cap=EVENT_CAP, first_stream=rank * B_PER_GPU,
-                                                         async_op=True, host_staging=(args.backend != "nccl"))
+        with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+            out, work = sed_amd.sharding.decode_and_exchange(det, table, 0.6, cap=EVENT_CAP, first_stream=rank * B_PER_GPU,
+                                                             async_op=True, host_staging=(args.backend != "nccl"))
         if work is not None:
             pending.append((out, work))
             say(f"step {i}: gather issued, {len(pending)} pending")
