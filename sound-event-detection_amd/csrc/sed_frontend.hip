@@ -304,6 +304,38 @@ __device__ __forceinline__ void mel_mfma_4frames(const FrontParams& p, const int
     constexpr int s = decltype(Sf)::value;
     boff[s] = (!Mel::kStatic || s < Mel::SETS) ? boffL[s * 64 + lane] : 0;
   });
+#ifndef SED_NO_MEL_ONE_BURST
+  if constexpr (Mel::kStatic && Mel::SETS * Mel::U <= 12) {
+    // Small compiled-in shapes: the operands of all sets are fetched in ONE burst (2 * SETS * U 16-byte reads, the
+    // transform registers are free by now), so the stage waits for the LDS once instead of once per set, and the
+    // instructions of the sets alternate, which also leaves no dependent pair back to back.
+    if (!SED_SKIP(32)) {
+      v4 a[Mel::SETS][Mel::U], bb[Mel::SETS][Mel::U], acc[Mel::SETS];
+      static_for<0, Mel::SETS>([&](auto Sf) {
+        constexpr int s = decltype(Sf)::value;
+        const float* bp = prow0 + (boff[s] & 0xffff);
+        const float* ap = mela + ((size_t)s * (Mel::U + 1) * 64 + lane) * 4;
+        static_for<0, Mel::U>([&](auto Uf) {
+          constexpr int u = decltype(Uf)::value;
+          a[s][u] = ld4(ap + 256 * u);
+          bb[s][u] = ld4(bp + 4 * u);
+        });
+        acc[s] = v4{0.0f, 0.0f, 0.0f, 0.0f};
+      });
+      SED_SCHED_FENCE();
+      static_for<0, Mel::U>([&](auto Uf) {
+        constexpr int u = decltype(Uf)::value;
+        static_for<0, Mel::SETS>([&](auto Sf) { constexpr int s = decltype(Sf)::value; acc[s] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[s][u].x, bb[s][u].x, acc[s], 0, 0, 0); });
+        static_for<0, Mel::SETS>([&](auto Sf) { constexpr int s = decltype(Sf)::value; acc[s] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[s][u].y, bb[s][u].y, acc[s], 0, 0, 0); });
+        static_for<0, Mel::SETS>([&](auto Sf) { constexpr int s = decltype(Sf)::value; acc[s] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[s][u].z, bb[s][u].z, acc[s], 0, 0, 0); });
+        static_for<0, Mel::SETS>([&](auto Sf) { constexpr int s = decltype(Sf)::value; acc[s] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[s][u].w, bb[s][u].w, acc[s], 0, 0, 0); });
+      });
+      static_for<0, Mel::SETS>([&](auto Sf) { constexpr int s = decltype(Sf)::value; st4(part + (boff[s] >> 16), acc[s]); });
+    }
+    wave_phase_fence();
+    return;
+  }
+#endif
   static_for<0, kMaxMelSets>([&](auto Sf) {
     constexpr int s = decltype(Sf)::value;
     if (s < sets) {
