@@ -286,6 +286,43 @@ template <class Mel> __device__ __forceinline__ int mel_u_of(const FrontParams& 
 template <class Mel> __device__ __forceinline__ int mel_maxpos_of(const FrontParams& p) { if constexpr (Mel::kStatic) return Mel::MAXPOS; else return p.mel_maxpos; }
 template <class Mel> __device__ __forceinline__ bool mel_two_rounds(const FrontParams& p) { if constexpr (Mel::kStatic) return Mel::ROUNDS > 1; else return p.n_quads > 16; }
 
+// Small compiled-in shapes: the operands of all accumulator sets (and of NG groups of 4 frames, `gpitch` floats apart)
+// are fetched in ONE burst of 2 * NG * SETS * U 16-byte reads (the transform registers are free by now), so the stage
+// waits for the LDS once instead of once per set and group, and the instructions of the chains alternate, which also
+// leaves no dependent pair back to back.  acc[g][s]: partial sums of set s for group g, as mel_mfma_4frames stores them.
+template <class Mel, int NG>
+__device__ __forceinline__ void mel_mfma_one_burst(const int (&boff)[kMaxMelSets], const float* prow0, int gpitch,
+                                                   const float* mela, v4 (&acc)[NG][Mel::SETS], int lane) {
+  v4 a[Mel::SETS][Mel::U], bb[NG][Mel::SETS][Mel::U];
+  static_for<0, Mel::SETS>([&](auto Sf) {
+    constexpr int s = decltype(Sf)::value;
+    const float* ap = mela + ((size_t)s * (Mel::U + 1) * 64 + lane) * 4;
+    static_for<0, Mel::U>([&](auto Uf) {
+      constexpr int u = decltype(Uf)::value;
+      a[s][u] = ld4(ap + 256 * u);
+      static_for<0, NG>([&](auto Gf) {
+        constexpr int g = decltype(Gf)::value;
+        bb[g][s][u] = ld4(prow0 + g * gpitch + (boff[s] & 0xffff) + 4 * u);
+      });
+    });
+    static_for<0, NG>([&](auto Gf) { acc[decltype(Gf)::value][s] = v4{0.0f, 0.0f, 0.0f, 0.0f}; });
+  });
+  SED_SCHED_FENCE();
+  static_for<0, Mel::U>([&](auto Uf) {
+    constexpr int u = decltype(Uf)::value;
+    static_for<0, 4>([&](auto Ef) {
+      constexpr int e = decltype(Ef)::value;
+      static_for<0, NG>([&](auto Gf) {
+        constexpr int g = decltype(Gf)::value;
+        static_for<0, Mel::SETS>([&](auto Sf) {
+          constexpr int s = decltype(Sf)::value;
+          acc[g][s] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[s][u][e], bb[g][s][u][e], acc[g][s], 0, 0, 0);
+        });
+      });
+    });
+  });
+}
+
 // Mel projection of 4 frames (power rows prow0 + j*PITCH, j = 0..3) on the matrix pipe.
 // Lane 4*block + j feeds the power of frame j as the B operand and the weight of filter 4*quad + j as the
 // A operand of block `block`; after the last instruction it holds, in acc[i], the partial sum of filter
@@ -306,31 +343,10 @@ __device__ __forceinline__ void mel_mfma_4frames(const FrontParams& p, const int
   });
 #ifndef SED_NO_MEL_ONE_BURST
   if constexpr (Mel::kStatic && Mel::SETS * Mel::U <= 12) {
-    // Small compiled-in shapes: the operands of all sets are fetched in ONE burst (2 * SETS * U 16-byte reads, the
-    // transform registers are free by now), so the stage waits for the LDS once instead of once per set, and the
-    // instructions of the sets alternate, which also leaves no dependent pair back to back.
     if (!SED_SKIP(32)) {
-      v4 a[Mel::SETS][Mel::U], bb[Mel::SETS][Mel::U], acc[Mel::SETS];
-      static_for<0, Mel::SETS>([&](auto Sf) {
-        constexpr int s = decltype(Sf)::value;
-        const float* bp = prow0 + (boff[s] & 0xffff);
-        const float* ap = mela + ((size_t)s * (Mel::U + 1) * 64 + lane) * 4;
-        static_for<0, Mel::U>([&](auto Uf) {
-          constexpr int u = decltype(Uf)::value;
-          a[s][u] = ld4(ap + 256 * u);
-          bb[s][u] = ld4(bp + 4 * u);
-        });
-        acc[s] = v4{0.0f, 0.0f, 0.0f, 0.0f};
-      });
-      SED_SCHED_FENCE();
-      static_for<0, Mel::U>([&](auto Uf) {
-        constexpr int u = decltype(Uf)::value;
-        static_for<0, Mel::SETS>([&](auto Sf) { constexpr int s = decltype(Sf)::value; acc[s] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[s][u].x, bb[s][u].x, acc[s], 0, 0, 0); });
-        static_for<0, Mel::SETS>([&](auto Sf) { constexpr int s = decltype(Sf)::value; acc[s] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[s][u].y, bb[s][u].y, acc[s], 0, 0, 0); });
-        static_for<0, Mel::SETS>([&](auto Sf) { constexpr int s = decltype(Sf)::value; acc[s] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[s][u].z, bb[s][u].z, acc[s], 0, 0, 0); });
-        static_for<0, Mel::SETS>([&](auto Sf) { constexpr int s = decltype(Sf)::value; acc[s] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[s][u].w, bb[s][u].w, acc[s], 0, 0, 0); });
-      });
-      static_for<0, Mel::SETS>([&](auto Sf) { constexpr int s = decltype(Sf)::value; st4(part + (boff[s] >> 16), acc[s]); });
+      v4 acc[1][Mel::SETS];
+      mel_mfma_one_burst<Mel, 1>(boff, prow0, 0, mela, acc, lane);
+      static_for<0, Mel::SETS>([&](auto Sf) { constexpr int s = decltype(Sf)::value; st4(part + (boff[s] >> 16), acc[0][s]); });
     }
     wave_phase_fence();
     return;
@@ -395,6 +411,57 @@ __device__ __forceinline__ v4 mel_gather_log(const FrontParams& p, const int32_t
     const v4 y = ld4(i0 + 1 < npos ? first + (i0 + 1) * kPartStride : zero4);
     sum += x + y;
   }
+  v4 val = sum;
+  if (p.log_kind == SED_LOG_DB10) {
+    val.x = 3.0102999566398120f * __log2f(fmaxf(sum.x, p.amin)) - p.db_offset;
+    val.y = 3.0102999566398120f * __log2f(fmaxf(sum.y, p.amin)) - p.db_offset;
+    val.z = 3.0102999566398120f * __log2f(fmaxf(sum.z, p.amin)) - p.db_offset;
+    val.w = 3.0102999566398120f * __log2f(fmaxf(sum.w, p.amin)) - p.db_offset;
+  } else if (p.log_kind == SED_LOG_LN) {
+    val.x = 0.6931471805599453f * __log2f(sum.x + p.ln_offset);
+    val.y = 0.6931471805599453f * __log2f(sum.y + p.ln_offset);
+    val.z = 0.6931471805599453f * __log2f(sum.z + p.ln_offset);
+    val.w = 0.6931471805599453f * __log2f(sum.w + p.ln_offset);
+  } else if (p.log_kind == SED_LOG_LN_FLOOR) {
+    val.x = 0.6931471805599453f * __log2f(fmaxf(sum.x, p.amin));
+    val.y = 0.6931471805599453f * __log2f(fmaxf(sum.y, p.amin));
+    val.z = 0.6931471805599453f * __log2f(fmaxf(sum.z, p.amin));
+    val.w = 0.6931471805599453f * __log2f(fmaxf(sum.w, p.amin));
+  }
+  const int m0 = 4 * (16 * r + (lane >> 2));
+  if (p.affine) val = __builtin_elementwise_fma(val, ld4(affL + m0), ld4(affL + 128 + m0));
+  return val;
+}
+
+// The gather in two halves, so that the reads of several gathers can be in flight before the first sum is formed.
+// Loads of one gather: the quad's first partial sum, then pairs (i0, i0 + 1) for i0 = 1, 3, .. below maxpos.
+template <class Mel> constexpr int gather_loads() { return Mel::kStatic ? 1 + 2 * (Mel::MAXPOS / 2) : 1 + 2 * 8; }
+template <class Mel>
+__device__ __forceinline__ void mel_gather_issue(const FrontParams& p, const int32_t* gwL, const float* zero4,
+                                                 const float* part, int r, int lane, v4 (&x)[gather_loads<Mel>()]) {
+  asm volatile("" : "+v"(lane));
+  const int g = gwL[r * 64 + lane];
+  const int npos = g >> 16;
+  const float* first = part + (g & 0xffff);
+  x[0] = ld4(first);  // every quad has at least one position
+  const int maxpos = mel_maxpos_of<Mel>(p);
+  static_for<1, gather_loads<Mel>()>([&](auto If) {
+    constexpr int i = decltype(If)::value;
+    constexpr int i0 = (i & 1) ? i : i - 1;  // the pair (i0, i0 + 1) is fetched when i0 < maxpos (wave-uniform)
+    if (i0 < maxpos) x[i] = ld4(i < npos ? first + i * kPartStride : zero4);
+    else x[i] = v4{0.0f, 0.0f, 0.0f, 0.0f};
+  });
+}
+template <class Mel>
+__device__ __forceinline__ v4 mel_gather_finish(const FrontParams& p, const float* affL, int r, int lane,
+                                                const v4 (&x)[gather_loads<Mel>()]) {
+  asm volatile("" : "+v"(lane));
+  v4 sum = x[0];
+  const int maxpos = mel_maxpos_of<Mel>(p);
+  static_for<0, (gather_loads<Mel>() - 1) / 2>([&](auto Tf) {
+    constexpr int i0 = 1 + 2 * decltype(Tf)::value;
+    if (i0 < maxpos) sum += x[i0] + x[i0 + 1];
+  });
   v4 val = sum;
   if (p.log_kind == SED_LOG_DB10) {
     val.x = 3.0102999566398120f * __log2f(fmaxf(sum.x, p.amin)) - p.db_offset;
@@ -593,6 +660,47 @@ stft_mel_kernel(const FrontParams p) {
           for (int k = lane; k < G::NBINS; k += 64) dst[(int64_t)f * G::NBINS + k] = X[f * G::PP + k];
       } else {
         float* part = X + p.part_off;
+#ifndef SED_NO_MEL_ONE_BURST
+        if constexpr (kGroups == 2 && Mel::kStatic && 2 * Mel::SETS * Mel::U <= 16) {
+          // Both groups of 4 frames in one pass: one burst of operand reads, then the partial sums of the first group,
+          // its gather reads, the partial sums of the second group (the LDS executes a wavefront's accesses in order, so
+          // they may reuse the area) and its gather reads, and one wait for all of them.
+          SED_P(5);
+          int lv = lane;
+          asm volatile("" : "+v"(lv));
+          int boff[kMaxMelSets];
+          static_for<0, kMaxMelSets>([&](auto Sf) {
+            constexpr int s = decltype(Sf)::value;
+            boff[s] = s < Mel::SETS ? boffL[s * 64 + lv] : 0;
+          });
+          v4 acc[2][Mel::SETS];
+          if (!SED_SKIP(32)) mel_mfma_one_burst<Mel, 2>(boff, X, 4 * G::PP, melaL, acc, lane);
+          wave_phase_fence();
+          SED_STAMP(5)
+          SED_P(6);
+          const int64_t s1 = (int64_t)nf0 * p.hop - p.pad_left;
+          if (!I16 && p.early && more && s1 >= 0 && s1 + dma_reach <= p.L && !SED_SKIP(1)) {
+            if constexpr (SKEW > 0) stage_span_dma_skewed<G, Mel::HOP, SKEW>(p, X, nb, s1, lane);
+            else stage_span_dma(p, X, nb, s1, lane);
+            staged = true;
+          }
+          if (!SED_SKIP(64)) {
+            v4 x[2][Mel::ROUNDS][gather_loads<Mel>()];
+            static_for<0, 2>([&](auto Gf) {
+              constexpr int g = decltype(Gf)::value;
+              static_for<0, Mel::SETS>([&](auto Sf) { constexpr int s = decltype(Sf)::value; st4(part + (boff[s] >> 16), acc[g][s]); });
+              wave_phase_fence();
+              static_for<0, Mel::ROUNDS>([&](auto Rf) { constexpr int r = decltype(Rf)::value; mel_gather_issue<Mel>(p, gwL, zeroL, part, r, lane, x[g][r]); });
+              wave_phase_fence();
+            });
+            static_for<0, 2>([&](auto Gf) {
+              constexpr int g = decltype(Gf)::value;
+              static_for<0, Mel::ROUNDS>([&](auto Rf) { constexpr int r = decltype(Rf)::value; hval[g][r] = mel_gather_finish<Mel>(p, affL, r, lane, x[g][r]); });
+            });
+          }
+          wave_phase_fence();
+        } else
+#endif
         static_for<0, kGroups>([&](auto Gf) {
           constexpr int g = decltype(Gf)::value;
           SED_P(5);
