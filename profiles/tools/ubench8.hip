@@ -104,9 +104,21 @@ double run(float* d) {
   float ms; (void)hipEventElapsedTime(&ms, e0, e1);
   return ms * 1e6 / iters;
 }
-int main() {
+#include <cstring>
+#include <cstdlib>
+int main(int argc, char** argv) {
   float* d;
   (void)hipMalloc(&d, 256 * 768 * 4);
+  if (argc > 2) {  // ubench8 v|l|x1 seconds: one configuration back to back, to sample the clock meanwhile
+    const double secs = atof(argv[2]);
+    double total = 0, last = 0;
+    while (total < secs * 1e9) {
+      last = !strcmp(argv[1], "v") ? run<0, true, false>(d) : !strcmp(argv[1], "l") ? run<1, false, true>(d) : run<1, true, true>(d);
+      total += last * 2000 * 2;
+    }
+    printf("%s: %.1f ns per round\n", argv[1], last);
+    return 0;
+  }
   run<0, true, true>(d);
   printf("per round of 12 wavefronts on a CU, ns:\n");
   printf("arithmetic alone (560 pk_fma)                    %7.1f\n", run<0, true, false>(d));
