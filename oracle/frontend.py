@@ -160,6 +160,26 @@ def windowed_dft_matrix(n_fft: int, window_full: np.ndarray):
     return np.cos(ang) * window_full[:, None], np.sin(ang) * window_full[:, None]
 
 
+def torchlibrosa_conv_weights(n_fft: int, window_full: np.ndarray):
+    """The fp32 tensors torchlibrosa 0.0.9 / 0.1.0 stores in stft.conv_real.weight / stft.conv_imag.weight, (F, 1, n_fft),
+    formed with the numpy expressions of its published source (torchlibrosa/stft.py, DFTBase.dft_matrix and
+    STFT.__init__; constructed at external/hts_audio_transformer/model/htsat.py:453-455):
+
+        (x, y) = np.meshgrid(np.arange(n), np.arange(n)); omega = np.exp(-2 * np.pi * 1j / n); W = np.power(omega, x * y)
+        conv_real.weight = torch.Tensor(np.real(W[:, 0:F] * fft_window[:, None]).T)[:, None, :]
+
+    np.power of a complex base goes through exp(y log x) for large exponents, so a few entries differ from the exactly
+    reduced angle of windowed_dft_matrix() by an fp32 ulp; this function is the recipe itself, run by the numpy installed
+    here (the library is not).
+    """
+    (x, y) = np.meshgrid(np.arange(n_fft), np.arange(n_fft))
+    omega = np.exp(-2 * np.pi * 1j / n_fft)
+    W = np.power(omega, x * y)
+    F = n_fft // 2 + 1
+    Ww = W[:, 0:F] * np.asarray(window_full, dtype=np.float64)[:, None]
+    return (np.real(Ww).T.astype(np.float32)[:, None, :], np.imag(Ww).T.astype(np.float32)[:, None, :])
+
+
 def power_spectrogram_gold(x, n_fft, hop, win_length=None, center=True, pad_mode="reflect",
                            window_full=None):
     """fp64 |STFT|^2, (..., T, F), with the exact fp64 window."""

@@ -240,14 +240,28 @@ class _ConvWeight(nn.Module):
 
 
 class _STFTTables(nn.Module):
-    def __init__(self, n_fft: int, window_full: torch.Tensor):
+    """stft.conv_real.weight / stft.conv_imag.weight as torchlibrosa's STFT module holds them (F, 1, n_fft): the Hann-windowed
+    DFT matrix, formed with the numpy expressions of torchlibrosa's DFTBase.dft_matrix / STFT.__init__ (omega ** (x * y) in
+    complex128, times the window, real and imaginary parts cast to fp32), so that a state_dict saved from this module
+    carries the values a torchlibrosa checkpoint carries (htsat.py:453-455, src/models/htsat/model.py:214-215).  About a
+    quarter of the entries differ by one fp32 ulp from the exactly reduced angle cos/sin(2 pi (n k mod N) / N).  The kernels
+    do not read these tensors."""
+
+    def __init__(self, n_fft: int, win_length: int):
         super().__init__()
-        n = torch.arange(n_fft, dtype=torch.float64)
-        k = torch.arange(n_fft // 2 + 1, dtype=torch.float64)
-        ang = -2.0 * math.pi * torch.remainder(torch.outer(k, n), n_fft) / n_fft
-        w = window_full.to(torch.float64)[None, :]
-        self.conv_real = _ConvWeight((torch.cos(ang) * w).to(torch.float32)[:, None, :].contiguous())
-        self.conv_imag = _ConvWeight((torch.sin(ang) * w).to(torch.float32)[:, None, :].contiguous())
+        # the fp64 window of scipy.signal.get_window('hann', win_length, fftbins=True) (general_cosine: 0.5 + 0.5 cos(fac),
+        # fac = linspace(-pi, pi, win_length + 1) without its last point), centred in n_fft samples like librosa.util.pad_center
+        fac = np.linspace(-np.pi, np.pi, win_length + 1)[:-1]
+        win = np.zeros(win_length)
+        for k, a in enumerate((0.5, 0.5)):
+            win += a * np.cos(k * fac)
+        lpad = (n_fft - win_length) // 2
+        window_full = np.pad(win, (lpad, n_fft - win_length - lpad))
+        (x, y) = np.meshgrid(np.arange(n_fft), np.arange(n_fft))
+        omega = np.exp(-2 * np.pi * 1j / n_fft)
+        W = np.power(omega, x * y)[:, 0:n_fft // 2 + 1] * window_full[:, None]
+        self.conv_real = _ConvWeight(torch.from_numpy(np.real(W).T.astype(np.float32))[:, None, :].contiguous())
+        self.conv_imag = _ConvWeight(torch.from_numpy(np.imag(W).T.astype(np.float32))[:, None, :].contiguous())
 
 
 class Spectrogram(_PlanHolder):
@@ -268,7 +282,7 @@ class Spectrogram(_PlanHolder):
         self.win_length = n_fft if win_length is None else win_length
         self.hop_length = int(self.win_length // 4) if hop_length is None else hop_length
         self.center, self.pad_mode, self.power = center, pad_mode, power
-        self.stft = _STFTTables(n_fft, hann_window(n_fft, self.win_length))
+        self.stft = _STFTTables(n_fft, self.win_length)
         self.register_load_state_dict_post_hook(_check_stft_tables)
 
     def _cfg(self) -> FrontendConfig:
@@ -289,7 +303,7 @@ class Spectrogram(_PlanHolder):
 
 
 def _check_stft_tables(module, incompatible_keys):
-    ref = _STFTTables(module.n_fft, hann_window(module.n_fft, module.win_length))
+    ref = _STFTTables(module.n_fft, module.win_length)
     for name in ("conv_real", "conv_imag"):
         got = getattr(module.stft, name).weight.detach().cpu()
         if not torch.allclose(got, getattr(ref, name).weight, atol=1e-5, rtol=0):

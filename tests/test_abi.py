@@ -96,6 +96,18 @@ def test_modules_construct_and_refuse_cpu_input():
     wr, wi = of.windowed_dft_matrix(1024, of.hann_periodic(1024))
     assert np.max(np.abs(s.stft.conv_real.weight[:, 0, :].numpy() - wr.T)) < 1e-6
     assert np.max(np.abs(s.stft.conv_imag.weight[:, 0, :].numpy() - wi.T)) < 1e-6
+    # the tensors of the state_dict are the ones torchlibrosa's own numpy recipe gives (omega ** (x * y) in complex128),
+    # bit for bit, at every size the library builds; they sit within one fp32 ulp (6e-8) of the exactly reduced angle, far
+    # inside the 1e-5 the load check allows
+    for n_fft in (512, 1024, 2048):
+        sp = s if n_fft == 1024 else sed_amd.Spectrogram(n_fft=n_fft, hop_length=n_fft // 4)
+        tr, ti = of.torchlibrosa_conv_weights(n_fft, of.pad_center(of.hann_periodic(n_fft), n_fft))
+        assert np.array_equal(sp.stft.conv_real.weight.numpy(), tr) and np.array_equal(sp.stft.conv_imag.weight.numpy(), ti)
+        er, ei = of.windowed_dft_matrix(n_fft, of.pad_center(of.hann_periodic(n_fft), n_fft))
+        assert np.max(np.abs(tr[:, 0, :] - er.T)) <= 6e-8 and np.max(np.abs(ti[:, 0, :] - ei.T)) <= 6e-8
+    sp = sed_amd.Spectrogram(n_fft=512, hop_length=160, win_length=400)  # a window shorter than the transform, centred
+    tr, ti = of.torchlibrosa_conv_weights(512, of.pad_center(of.hann_periodic(400), 512))
+    assert np.array_equal(sp.stft.conv_real.weight.numpy(), tr) and np.array_equal(sp.stft.conv_imag.weight.numpy(), ti)
     with pytest.raises(RuntimeError, match="no CPU path"):
         s(torch.zeros(1, 4096))
     with pytest.raises(RuntimeError, match="no CPU path"):
