@@ -92,7 +92,9 @@ const char* sed_status_string(int status);
  * external/hts_audio_transformer/model/htsat.py:457; SED_MEL_HTK_TF = tf.signal.linear_to_mel_weight_matrix
  * (the YAMNet graph behind src/models/yamnet_train.py:47); SED_MEL_KALDI = torchaudio.compliance.kaldi.get_mel_banks
  * (low_freq fmin, high_freq fmax, no VTLN) with a zero row for the Nyquist bin, as kaldi.fbank applies it
- * (external/audio_mamba/src/dataloader.py:133).  fp64 arithmetic, rounded once to fp32. */
+ * (external/audio_mamba/src/dataloader.py:133).  fp64 arithmetic, rounded once to fp32; SED_MEL_SLANEY follows librosa
+ * operation for operation instead (rfftfreq bin frequencies, triangles rounded to fp32, then scaled by the fp64 Slaney
+ * factor and rounded again, as its in-place `weights *= enorm` on an fp32 array does). */
 int sed_mel_filterbank(int32_t mel_kind, int32_t sample_rate, int32_t n_fft, int32_t n_mels, float fmin, float fmax,
                        float* melW_host);
 

@@ -78,23 +78,26 @@ def mel_to_hz_slaney(m):
 
 
 def librosa_mel(sr, n_fft, n_mels=128, fmin=0.0, fmax=None) -> np.ndarray:
-    """librosa.filters.mel(htk=False, norm='slaney') -> (n_mels, 1+n_fft//2) fp32."""
+    """librosa.filters.mel(htk=False, norm='slaney') -> (n_mels, 1+n_fft//2) fp32, operation for operation as
+    librosa 0.10 / 0.11 forms it (the reference ran 0.11.0): bin frequencies from np.fft.rfftfreq (k * (1 / (n_fft * (1 / sr)))),
+    the triangles stored into an fp32 array, then the Slaney area normalisation applied in place (`weights *= enorm`:
+    the fp32 values times the fp64 factor, rounded to fp32 again), i.e. two roundings, not one."""
     if fmax is None:
         fmax = float(sr) / 2
     n_bins = 1 + n_fft // 2
-    fftfreqs = np.linspace(0.0, float(sr) / 2, n_bins)  # == rfftfreq
+    fftfreqs = np.fft.rfftfreq(n=n_fft, d=1.0 / sr)
     mel_pts = np.linspace(hz_to_mel_slaney(fmin), hz_to_mel_slaney(fmax), n_mels + 2)
     mel_f = mel_to_hz_slaney(mel_pts)
     fdiff = np.diff(mel_f)
-    ramps = mel_f[:, None] - fftfreqs[None, :]
-    weights = np.zeros((n_mels, n_bins), dtype=np.float64)
+    ramps = np.subtract.outer(mel_f, fftfreqs)
+    weights = np.zeros((n_mels, n_bins), dtype=np.float32)
     for i in range(n_mels):
         lower = -ramps[i] / fdiff[i]
         upper = ramps[i + 2] / fdiff[i + 1]
-        weights[i] = np.maximum(0.0, np.minimum(lower, upper))
+        weights[i] = np.maximum(0, np.minimum(lower, upper))
     enorm = 2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels])
-    weights *= enorm[:, None]
-    return weights.astype(np.float32)
+    weights *= enorm[:, np.newaxis]
+    return weights
 
 
 def tf_linear_to_mel_weight_matrix(num_mel_bins=64, num_spectrogram_bins=257, sample_rate=16000,

@@ -70,20 +70,24 @@ inline double mel_to_hz_slaney(double m) {
   return m >= min_log_mel ? min_log_hz * std::exp(logstep * (m - min_log_mel)) : f_sp * m;
 }
 
-// librosa.filters.mel(htk=False, norm='slaney') transposed: melW[k*n_mels + m], k = 0..n_fft/2.
+// librosa.filters.mel(htk=False, norm='slaney') transposed: melW[k*n_mels + m], k = 0..n_fft/2.  Operation for operation
+// as librosa forms it: bin frequencies k * (1 / (n_fft * (1 / sr))) (np.fft.rfftfreq), the triangle rounded to fp32 (it is
+// stored into an fp32 array), then multiplied by the fp64 Slaney factor and rounded to fp32 again (`weights *= enorm`).
 inline std::vector<float> mel_slaney(int sr, int n_fft, int n_mels, double fmin, double fmax) {
   const int F = n_fft / 2 + 1;
   std::vector<double> pts = linspace(hz_to_mel_slaney(fmin), hz_to_mel_slaney(fmax), n_mels + 2);
   for (double& p : pts) p = mel_to_hz_slaney(p);
-  const std::vector<double> freqs = linspace(0.0, (double)sr / 2, F);
+  const double d = 1.0 / (double)sr;
+  const double val = 1.0 / ((double)n_fft * d);
   std::vector<float> w((size_t)F * n_mels, 0.0f);
   for (int m = 0; m < n_mels; ++m) {
     const double enorm = 2.0 / (pts[m + 2] - pts[m]);
     for (int k = 0; k < F; ++k) {
-      const double f = freqs[k];
-      const double lower = (f - pts[m]) / (pts[m + 1] - pts[m]);
+      const double f = (double)k * val;
+      const double lower = -(pts[m] - f) / (pts[m + 1] - pts[m]);
       const double upper = (pts[m + 2] - f) / (pts[m + 2] - pts[m + 1]);
-      w[(size_t)k * n_mels + m] = (float)(std::max(0.0, std::min(lower, upper)) * enorm);
+      const float tri = (float)std::max(0.0, std::min(lower, upper));
+      w[(size_t)k * n_mels + m] = (float)((double)tri * enorm);
     }
   }
   return w;
