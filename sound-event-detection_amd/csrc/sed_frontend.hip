@@ -39,6 +39,9 @@ using Geo2048 = Geo<32, 32, 16, 8>;
 #define SED_WPE(x) (x)   // experiments: -DSED_WPE(x)=4 asks the register allocator for 4 wavefronts per SIMD
 #endif
 
+#ifndef SED_BURST2048
+#define SED_BURST2048 24
+#endif
 constexpr int kMaxMelSets = 4;
 constexpr int kMelBurst = 8;    // steps of 4 bins whose MFMA operands are fetched from LDS in one burst
 constexpr int kPartStride = 20;  // floats between the partial sums of consecutive positions: [frame][filter] + pad (4*odd: bank spread)
@@ -330,7 +333,7 @@ __device__ __forceinline__ void mel_mfma_one_burst(const int (&boff)[kMaxMelSets
 // set, so an odd step count needs no special case.  The partial sums go to LDS, kPartStride floats per slot; which
 // slot a block fills comes from the lane's table word (blocks are placed for bank-conflict-free operand reads, slots
 // follow the quads).
-template <class Mel>
+template <class Mel, int BURST_STEPS = 12>
 __device__ __forceinline__ void mel_mfma_4frames(const FrontParams& p, const int32_t* boffL, const float* prow0,
                                                  const float* mela, float* part, int lane) {
   asm volatile("" : "+v"(lane));  // keeps the per-lane table reads inside the streaming loop instead of pinning registers
@@ -342,7 +345,7 @@ __device__ __forceinline__ void mel_mfma_4frames(const FrontParams& p, const int
     boff[s] = (!Mel::kStatic || s < Mel::SETS) ? boffL[s * 64 + lane] : 0;
   });
 #ifndef SED_NO_MEL_ONE_BURST
-  if constexpr (Mel::kStatic && Mel::SETS * Mel::U <= 12) {
+  if constexpr (Mel::kStatic && Mel::SETS * Mel::U <= BURST_STEPS) {
     if (!SED_SKIP(32)) {
       v4 acc[1][Mel::SETS];
       mel_mfma_one_burst<Mel, 1>(boff, prow0, 0, mela, acc, lane);
@@ -704,7 +707,8 @@ stft_mel_kernel(const FrontParams p) {
         static_for<0, kGroups>([&](auto Gf) {
           constexpr int g = decltype(Gf)::value;
           SED_P(5);
-          mel_mfma_4frames<Mel>(p, boffL, X + 4 * g * G::PP, melaL, part, lane);
+          // (the n_fft 2048 kernels may use 256 registers: their larger shapes fit one burst too)
+          mel_mfma_4frames<Mel, (G::NFFT == 2048 ? SED_BURST2048 : 12)>(p, boffL, X + 4 * g * G::PP, melaL, part, lane);
           SED_STAMP(5)
           SED_P(6);
           if constexpr (g == kGroups - 1) {
