@@ -559,9 +559,43 @@ __global__ void __launch_bounds__(256) wav2img_kernel(const float* x, int T, int
   const int hi = min(T - 1, (int)floorf(scale * (float)(t0 + n_out - 1)) + 2);
   const int n_rows = hi - lo + 1, pitch = M + 1;
   const float* src = x + ((int64_t)b * T + lo) * M;
-  for (int i = threadIdx.x; i < n_rows * M; i += 256) rows[(i / M) * pitch + i % M] = src[i];
+  // staging: 16 bytes per load when the rows allow it (the tile's rows are contiguous in memory)
+  if (M % 4 == 0 && ((uintptr_t)src & 15) == 0) {
+    for (int i4 = threadIdx.x; i4 < n_rows * (M / 4); i4 += 256) {
+      const float4 v = reinterpret_cast<const float4*>(src)[i4];
+      const int row = i4 / (M / 4), col = 4 * (i4 % (M / 4));
+      float* d = rows + row * pitch + col;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+  } else {
+    for (int i = threadIdx.x; i < n_rows * M; i += 256) rows[(i / M) * pitch + i % M] = src[i];
+  }
   __syncthreads();
   const float A = -0.75f;
+  if (n_out == 64) {
+    // full tile: a thread keeps its image column (u = thread % 64), so its source frames and the four weights are formed
+    // once and the loop over the mel rows is four LDS reads, the weighted sum and one store (64 consecutive columns =
+    // 256 bytes per wavefront)
+    const int u = threadIdx.x & 63, f0 = threadIdx.x >> 6;
+    const int t = t0 + u;
+    float* o = img + (((int64_t)b * ratio + r) * M) * seg + u0 + u;
+    if (T == target_T) {
+      const float* p0 = rows + (t - lo) * pitch;
+      for (int f = f0; f < M; f += 4) o[(int64_t)f * seg] = p0[f];
+    } else {
+      const float real = scale * (float)t;
+      const float fl = floorf(real);
+      const int k = (int)fl;
+      const float tt = real - fl;
+      const float c0 = cubic2(tt + 1.0f, A), c1 = cubic1(tt, A), c2 = cubic1(1.0f - tt, A), c3 = cubic2(2.0f - tt, A);
+      const float* p0 = rows + (min(max(k - 1, 0), T - 1) - lo) * pitch;
+      const float* p1 = rows + (min(max(k, 0), T - 1) - lo) * pitch;
+      const float* p2 = rows + (min(max(k + 1, 0), T - 1) - lo) * pitch;
+      const float* p3 = rows + (min(max(k + 2, 0), T - 1) - lo) * pitch;
+      for (int f = f0; f < M; f += 4) o[(int64_t)f * seg] = p0[f] * c0 + p1[f] * c1 + p2[f] * c2 + p3[f] * c3;
+    }
+    return;
+  }
   for (int i = threadIdx.x; i < n_out * M; i += 256) {
     const int u = i % n_out, f = i / n_out;     // consecutive threads -> consecutive image columns
     const int t = t0 + u;
