@@ -21,3 +21,33 @@ for name, shape, kw in (("reshape_wav2img 256 x (1001, 64) -> 256 x 256", (256, 
     img = sed_amd.reshape_wav2img(lm, **kw)
     us = timeit(lambda: sed_amd.reshape_wav2img(lm, **kw))
     print(f"{name:52s} {us:7.1f} us  {(lm.numel() + img.numel()) * 4 / us / 1e6:5.2f} TB/s  digest {dig(img)}")
+from sed_amd import decode as D
+for name, shape, ratio, frames in (("interpolate_and_pad 256 x (128, 6) x 32 -> 4096", (256, 128, 6), 32, 4096),
+                                   ("interpolate_and_pad 64 x (128, 527) x 32 -> 4096", (64, 128, 527), 32, 4096)):
+    x = torch.rand(shape, generator=g, device=dev)
+    y = D.interpolate_and_pad(x, ratio, frames)
+    us = timeit(lambda: D.interpolate_and_pad(x, ratio, frames))
+    print(f"{name:52s} {us:7.1f} us  {(x.numel() + y.numel()) * 4 / us / 1e6:5.2f} TB/s  digest {dig(y)}")
+# unfused parity path: Spectrogram (writes (B, T, 513)) and LogmelFilterBank on it
+x = 0.1 * torch.randn((64, 320000), generator=g, device=dev)
+sp = sed_amd.Spectrogram(n_fft=1024, hop_length=320)
+lf = sed_amd.LogmelFilterBank(sr=32000, n_fft=1024, n_mels=64, fmin=50, fmax=14000, top_db=None)
+s = sp(x)
+us = timeit(lambda: sp(x), n=50)
+print(f"{'Spectrogram 64 x 10 s (unfused)':52s} {us:7.1f} us  {(x.numel() + s.numel()) * 4 / us / 1e6:5.2f} TB/s  digest {dig(s)}")
+m = lf(s)
+us = timeit(lambda: lf(s), n=50)
+print(f"{'LogmelFilterBank on it (unfused)':52s} {us:7.1f} us  {(s.numel() + m.numel()) * 4 / us / 1e6:5.2f} TB/s  digest {dig(m)}")
+# dB post-pass of the librosa flavour: per-clip max, subtract, floor (128 clips x (862, 64))
+db = -60.0 * torch.rand((128, 862, 64), generator=g, device=dev)
+from sed_amd import frontend as FE
+import sed_amd._lib as L
+def dbn():
+    t = db.clone()
+    with torch.cuda.device(dev):
+        L.check(L.lib.sed_db_normalize(t.data_ptr(), 128, 862 * 64, 1, 80.0, L.stream_ptr(dev)), "db")
+    return t
+t = dbn()
+us_clone = timeit(lambda: db.clone())
+us = timeit(dbn)
+print(f"{'sed_db_normalize 128 x (862, 64)':52s} {us - us_clone:7.1f} us (clone {us_clone:.1f} subtracted)  {2 * db.numel() * 4 / max(us - us_clone, 1e-3) / 1e6:5.2f} TB/s  digest {dig(t)}")
