@@ -651,7 +651,7 @@ extern "C" int sed_htsat_repeat2img(const float* logmel, int64_t B, int64_t T, i
 
 // ---- framewise output of the detector back on the input's frame grid ------------------------------------------
 // interpolate(x, ratio) followed by pad_framewise_output(., frames_out): out[b][t][c] = x[b][min(t / ratio, T-1)][c].
-__global__ void __launch_bounds__(256) framewise_expand_kernel(const float* x, int64_t T, int64_t C, int ratio,
+__global__ void __launch_bounds__(256) framewise_expand_any_kernel(const float* x, int64_t T, int64_t C, int ratio,
                                                                int64_t frames_out, int64_t total, float* out) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int64_t c = i % C, bt = i / C;
@@ -661,14 +661,55 @@ __global__ void __launch_bounds__(256) framewise_expand_kernel(const float* x, i
   }
 }
 
+// One workgroup per (source frame ts, clip b): the frame's C values go to LDS once and are written out `reps` times in a
+// row (ratio copies, and for the last frame also the padding up to frames_out), a contiguous run of reps * C floats.
+// The class index of a thread's element advances by 256 mod C from one store to the next, so there is no division in
+// the loop (the element-per-thread kernel above, four 64-bit divisions per element, reaches 1.4 .. 1.8 TB/s).
+__global__ void __launch_bounds__(256) framewise_expand_kernel(const float* x, int T, int C, int ratio, int64_t frames_out,
+                                                               int G, float* out) {
+  // G > 1 (few classes): the workgroup takes G consecutive source frames, so that it has a few thousand floats to write
+  extern __shared__ float row[];
+  const int ts0 = blockIdx.x * G, b = blockIdx.y;
+  const int nts = min(G, T - ts0);
+  const float* src = x + ((int64_t)b * T + ts0) * C;
+  for (int c = threadIdx.x; c < nts * C; c += 256) row[c] = src[c];
+  __syncthreads();
+  const int64_t first = (int64_t)ts0 * ratio;                                            // first output frame of the chunk
+  const int64_t last = ts0 + nts == T ? frames_out : min(first + (int64_t)nts * ratio, frames_out);  // one past its last
+  if (last <= first) return;
+  const int64_t n = (last - first) * C;
+  float* o = out + ((int64_t)b * frames_out + first) * C;
+  if (G == 1) {
+    const int step = 256 % C;
+    int c = threadIdx.x % C;
+    for (int64_t j = threadIdx.x; j < n; j += 256) {
+      o[j] = row[c];
+      c += step;
+      if (c >= C) c -= C;
+    }
+  } else {  // n is small here (the host picks G for about 4096 floats, the padding of the last chunk aside)
+    for (int64_t j = threadIdx.x; j < n; j += 256) {
+      const int q = (int)(j / C), c = (int)(j - (int64_t)q * C);  // output frame of the chunk, class
+      o[j] = row[min(q / ratio, nts - 1) * C + c];
+    }
+  }
+}
+
 extern "C" int sed_framewise_expand(const float* x, int64_t B, int64_t T, int64_t C, int32_t ratio, int64_t frames_out,
                                     float* out, void* stream) {
   if (B < 0 || T < 1 || C < 1 || ratio < 1 || frames_out < 0) return SED_ERR_BAD_ARG;
   const int64_t total = B * frames_out * C;
   if (total == 0) return SED_OK;
   if (!x || !out) return SED_ERR_BAD_ARG;
-  const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 256 * 32);
-  hipLaunchKernelGGL(framewise_expand_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, T, C, (int)ratio,
-                     frames_out, total, out);
+  if (B <= 65535 && T <= INT32_MAX / 2 && C <= 8192) {
+    const int64_t per_frame = (int64_t)ratio * C;
+    const int G = per_frame >= 2048 ? 1 : (int)std::min<int64_t>(T, std::max<int64_t>(1, 4096 / per_frame));
+    hipLaunchKernelGGL(framewise_expand_kernel, dim3((unsigned)((T + G - 1) / G), (unsigned)B), dim3(256),
+                       (size_t)G * C * sizeof(float), (hipStream_t)stream, x, (int)T, (int)C, (int)ratio, frames_out, G, out);
+  } else {
+    const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(framewise_expand_any_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, T, C, (int)ratio,
+                       frames_out, total, out);
+  }
   return hip_status(hipGetLastError());
 }

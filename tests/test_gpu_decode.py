@@ -265,7 +265,8 @@ def test_framewise_interpolate_and_pad():
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(12)
     for (B, T, C, ratio, frames) in ((1, 128, 6, 32, 4096), (3, 7, 6, 32, 250), (2, 31, 5, 1, 40), (4, 1, 3, 8, 8),
-                                     (1, 33, 527, 32, 1056)):
+                                     (1, 33, 527, 32, 1056), (2, 50, 300, 4, 230), (1, 3, 9000, 2, 9),
+                                     (5, 100, 1, 32, 3300), (2, 9, 64, 32, 288), (3, 40, 17, 5, 333)):
         p = rng.random((B, T, C)).astype(np.float32)
         pd = torch.from_numpy(p).to(dev)
         up = sed_amd.interpolate(pd, ratio)
