@@ -774,6 +774,9 @@ struct MelRowsParams {
 };
 
 // 16 lanes per row, 16 rows per workgroup pass; every lane evaluates its share of the banded filters.
+// NV = values per thread of a tile of 16 rows (ceil(16 * nbins / 256)).  The next tile's values are loaded into registers
+// while the current tile is summed, so a workgroup never waits for global memory with nothing else to do.
+template <int NV>
 __global__ void __launch_bounds__(256) mel_rows_kernel(const MelRowsParams p) {
   extern __shared__ __align__(16) float smem[];
   const int tid = threadIdx.x;
@@ -784,14 +787,37 @@ __global__ void __launch_bounds__(256) mel_rows_kernel(const MelRowsParams p) {
   float* melwL = (float*)(metaL + 16 * p.slots);
   for (int i = tid; i < 16 * p.slots; i += 256) metaL[i] = p.meta[i];
   for (int i = tid; i < p.wcount; i += 256) melwL[i] = p.melw[i];
-  for (int64_t r0 = (int64_t)blockIdx.x * 16; r0 < p.rows; r0 += (int64_t)gridDim.x * 16) {
+  // a tile's rows are contiguous in memory: element tid + 256 j of the tile for j = 0..NV-1 (clamped addresses, never
+  // predicated loads)
+  float v[NV];
+  auto fetch = [&](int64_t r0) {
+    const int n = (int)min((int64_t)16, p.rows - r0) * p.nbins;
+    const float* src = p.spec + r0 * p.nbins;
+    static_for<0, NV>([&](auto Kf) {
+      constexpr int j = decltype(Kf)::value;
+      v[j] = src[min(tid + 256 * j, n - 1)];
+    });
+  };
+  const int64_t stride = (int64_t)gridDim.x * 16;
+  int64_t r0 = (int64_t)blockIdx.x * 16;
+  if (r0 < p.rows) fetch(r0);
+  for (; r0 < p.rows; r0 += stride) {
     const int nr = (int)min((int64_t)16, p.rows - r0);
-    __syncthreads();
-    for (int i = tid; i < nr * p.nbins; i += 256) {
-      const int r = i / p.nbins, k = i - r * p.nbins;
-      rowsL[r * pitch + k] = p.spec[(r0 + r) * p.nbins + k];
+    const int n = nr * p.nbins;
+    __syncthreads();  // the previous tile's sums and stores are done with the LDS
+    {
+      // row and bin of a thread's element advance by 256 from one to the next (a row has more than 256 bins, so at most
+      // one wrap per step)
+      int r = tid / p.nbins, k = tid - r * p.nbins;
+      static_for<0, NV>([&](auto Kf) {
+        constexpr int j = decltype(Kf)::value;
+        if (tid + 256 * j < n) rowsL[r * pitch + k] = v[j];
+        k += 256;
+        if (k >= p.nbins) { k -= p.nbins; ++r; }
+      });
     }
     __syncthreads();
+    if (r0 + stride < p.rows) fetch(r0 + stride);  // in flight during the sums
     const int r = tid >> 4, l = tid & 15;
     if (r < nr) {
       for (int j = 0; j < p.slots; ++j) {
@@ -801,9 +827,9 @@ __global__ void __launch_bounds__(256) mel_rows_kernel(const MelRowsParams p) {
         const float* w = melwL + e.woff;
         float acc = 0.0f;
         for (int i = 0; i < e.len; ++i) acc = __builtin_fmaf(x[i], w[i], acc);
-        float v = log_epilogue(acc, p.log_kind, p.amin, p.db_offset, p.ln_offset);
-        if (p.affine) v = __builtin_fmaf(v, p.aff_scale[e.mel], p.aff_shift[e.mel]);
-        melbuf[r * p.n_mels + e.mel] = v;
+        float val = log_epilogue(acc, p.log_kind, p.amin, p.db_offset, p.ln_offset);
+        if (p.affine) val = __builtin_fmaf(val, p.aff_scale[e.mel], p.aff_shift[e.mel]);
+        melbuf[r * p.n_mels + e.mel] = val;
       }
     }
     __syncthreads();
@@ -1406,11 +1432,25 @@ extern "C" int sed_mel_from_spectrogram(const sed_plan* pl, const float* spec, i
   p.aff_shift = pl->d_shift;
   const size_t lds = sizeof(float) * (((16 * (p.nbins + 3) + 16 * p.n_mels + 3) & ~3) + 4 * 16 * p.slots + p.wcount);
   if (lds > 160 * 1024) return SED_ERR_BAD_ARG;
-  SED_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mel_rows_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  auto kfn = c.n_fft == 512 ? mel_rows_kernel<17> : c.n_fft == 1024 ? mel_rows_kernel<33> : mel_rows_kernel<65>;
+  const void* kern = reinterpret_cast<const void*>(kfn);
+  {
+    // the dynamic LDS limit is a property of the kernel function: set once per kernel and device to the hardware maximum,
+    // so that concurrent launches with different sizes never race on it
+    static std::mutex mu;
+    static std::vector<std::pair<const void*, int>> done;
+    std::lock_guard<std::mutex> lock(mu);
+    const std::pair<const void*, int> key{kern, pl->device};
+    if (std::find(done.begin(), done.end(), key) == done.end()) {
+      SED_HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      done.push_back(key);
+    }
+  }
   const int64_t groups = (rows + 15) / 16;
-  const int grid = (int)std::min<int64_t>(groups, (int64_t)pl->num_cus * 2);
-  hipLaunchKernelGGL(mel_rows_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
+  // as many workgroups per CU as the LDS holds (the tiles are latency-bound: load, barrier, short sums, barrier, store)
+  const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds));
+  const int grid = (int)std::min<int64_t>(groups, (int64_t)pl->num_cus * per_cu);
+  hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
   return hip_status(hipGetLastError());
 }
 
