@@ -51,3 +51,12 @@ t = dbn()
 us_clone = timeit(lambda: db.clone())
 us = timeit(dbn)
 print(f"{'sed_db_normalize 128 x (862, 64)':52s} {us - us_clone:7.1f} us (clone {us_clone:.1f} subtracted)  {2 * db.numel() * 4 / max(us - us_clone, 1e-3) / 1e6:5.2f} TB/s  digest {dig(t)}")
+# detector -> classifier hand-off: 2048 events of 1..3 s cut out of 256 x 10 s @ 32 kHz into a (2048, 96000) batch
+import numpy as np
+rng = np.random.default_rng(0)
+pcm = 0.1 * torch.randn((256, 320000), generator=g, device=dev)
+ev = [(int(rng.integers(256)), float(a), float(a + d)) for a, d in zip(rng.uniform(0, 7, 2048), rng.uniform(1, 3, 2048))]
+clips, lens = sed_amd.cut_events(pcm, 32000, ev, cap=96000)
+us = timeit(lambda: sed_amd.cut_events(pcm, 32000, ev, cap=96000), n=30)
+moved = int(lens.clamp(max=96000).sum().item()) * 4 + clips.numel() * 4
+print(f"{'cut_events 2048 x <= 3 s -> (2048, 96000)':52s} {us:7.1f} us  {moved / us / 1e6:5.2f} TB/s  digest {dig(clips[:64])}")
