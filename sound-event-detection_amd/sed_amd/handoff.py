@@ -32,10 +32,13 @@ def cut_events(pcm: torch.Tensor, sr, events: Sequence[Tuple[int, float, float]]
     # stride(0) < n, which the kernel would index as if rows were n apart
     if pcm.stride(1) != 1 or (S > 1 and pcm.stride(0) < n):
         pcm = pcm.contiguous()
-    idx = np.array([int(e[0]) for e in events], dtype=np.int32)
-    start = np.array([int(e[1] * sr) for e in events], dtype=np.int64)     # cut_audio.py:37-38
-    end = np.array([int(e[2] * sr) for e in events], dtype=np.int64)
     E = len(events)
+    # int(start_sec * sr), int(end_sec * sr) of cut_audio.py:37-38 for all events at once: the fp64 product of Python's
+    # float arithmetic, truncated toward zero as int() does
+    ev = np.asarray(events, dtype=np.float64).reshape(E, 3)
+    idx = ev[:, 0].astype(np.int32)
+    start = np.trunc(ev[:, 1] * sr).astype(np.int64)
+    end = np.trunc(ev[:, 2] * sr).astype(np.int64)
     if cap is None:
         a = np.clip(np.where(start < 0, start + n, start), 0, n)
         b = np.clip(np.where(end < 0, end + n, end), 0, n)
@@ -45,7 +48,14 @@ def cut_events(pcm: torch.Tensor, sr, events: Sequence[Tuple[int, float, float]]
     lengths = torch.empty((E,), dtype=torch.int32, device=dev)
     if E == 0:
         return clips, lengths
-    d_idx, d_start, d_end = (torch.from_numpy(a).to(dev) for a in (idx, start, end))
+    # one upload for the three index arrays: [start int64 | end int64 | stream int32]
+    packed = np.empty(20 * E, dtype=np.uint8)
+    packed[:8 * E] = start.view(np.uint8)
+    packed[8 * E:16 * E] = end.view(np.uint8)
+    packed[16 * E:] = idx.view(np.uint8)
+    d_packed = torch.from_numpy(packed).to(dev)
+    d_start, d_end = d_packed[:8 * E].view(torch.int64), d_packed[8 * E:16 * E].view(torch.int64)
+    d_idx = d_packed[16 * E:].view(torch.int32)
     with torch.cuda.device(dev):
         L.check(L.lib.sed_cut_events(pcm.data_ptr(), L.PCM_I16 if pcm.dtype == torch.int16 else L.PCM_F32,
                                      float(pcm_divisor), S, n, max(pcm.stride(0), n), d_idx.data_ptr(), d_start.data_ptr(),
