@@ -171,17 +171,23 @@ def detect_onsets_offsets_batch(preds, threshold=0.5, hop_time=0.48, med_filter=
     B, N = p.shape
     runs, counts = threshold_runs(p[:, :, None], threshold, "median3" if med_filter else None)
     runs, counts = runs[:, 0].cpu().numpy(), counts[:, 0].cpu().numpy()
+    # All streams at once: the reference diffs the UNPADDED trace, so a run starting at frame 0 has no onset and one
+    # ending at N no offset; times are frame * hop_time in fp64 (np.int64 * float, as the reference's array product).
+    cap = runs.shape[1]
+    live = np.arange(cap)[None, :] < counts[:, None]
+    on_ok = live & (runs[:, :, 0] >= 1)
+    off_ok = live & (runs[:, :, 1] <= N - 1)
+    on_t = runs[:, :, 0][on_ok].astype(np.int64) * hop_time           # row-major: stream by stream, in run order
+    off_t = runs[:, :, 1][off_ok].astype(np.int64) * hop_time
+    n_on, n_off = on_ok.sum(axis=1), off_ok.sum(axis=1)
+    on_parts = np.split(on_t, np.cumsum(n_on)[:-1]) if B else []
+    off_parts = np.split(off_t, np.cumsum(n_off)[:-1]) if B else []
     out = []
     for b in range(B):
-        r = runs[b, :counts[b]]
-        # the reference diffs the UNPADDED trace: a run starting at frame 0 has no onset, one ending at N no offset
-        on_k = r[r[:, 0] >= 1, 0].astype(np.int64)
-        off_k = r[r[:, 1] <= N - 1, 1].astype(np.int64)
-        onsets = on_k * hop_time
-        offsets = off_k * hop_time
-        if len(offsets) < len(onsets):
+        onsets, offsets = on_parts[b], off_parts[b]
+        if n_off[b] < n_on[b]:
             offsets = np.append(offsets, (N + 1) * hop_time)
-        elif len(offsets) > len(onsets):
+        elif n_off[b] > n_on[b]:
             onsets = np.append(0, onsets)
         out.append((onsets, offsets))
     return out
