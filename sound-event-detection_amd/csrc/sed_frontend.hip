@@ -658,9 +658,20 @@ stft_mel_kernel(const FrontParams p) {
       const int nf0 = (gi - nb * p.groups_per_clip) * G::FPW;
       staged = false;
       if constexpr (SPEC_OUT) {
+        // the group's rows are one contiguous run of nvalid * NBINS floats in the (T, F) output: a few scalar stores up to
+        // the first 16-byte boundary, then 16 bytes per lane (the four values of a vector may sit in two power rows)
         float* dst = p.out + (int64_t)b * p.out_stride_b + (int64_t)f0 * G::NBINS;
-        for (int f = 0; f < nvalid; ++f)
-          for (int k = lane; k < G::NBINS; k += 64) dst[(int64_t)f * G::NBINS + k] = X[f * G::PP + k];
+        const int n = nvalid * G::NBINS;
+        const int head = min(n, (int)((4 - (((uintptr_t)dst >> 2) & 3)) & 3));
+        const int nvec = (n - head) >> 2;
+        auto at = [&](int e) { const int f = e / G::NBINS; return X[f * G::PP + (e - f * G::NBINS)]; };
+        if (lane < head) dst[lane] = at(lane);
+        for (int j = lane; j < nvec; j += 64) {
+          const int e = head + 4 * j;
+          st4(dst + e, v4{at(e), at(e + 1), at(e + 2), at(e + 3)});
+        }
+        const int tail0 = head + 4 * nvec;
+        if (tail0 + lane < n) dst[tail0 + lane] = at(tail0 + lane);
       } else {
         float* part = X + p.part_off;
 #ifndef SED_NO_MEL_ONE_BURST
