@@ -154,6 +154,18 @@ int sed_mel_from_spectrogram(const sed_plan* plan, const float* spec, int64_t ro
  * top_db=80) per clip (audio_to_spectrograms.py:43) and torchlibrosa's top_db over the whole tensor. */
 int sed_db_normalize(float* x, int64_t groups, int64_t group_elems, int32_t subtract_max, float top_db,
                      void* stream);
+/* (With fewer than 64 groups of more than 65536 floats each, sed_db_normalize cuts the groups into pieces and keeps their
+ * partial maxima in a stream-ordered allocation, hipMallocAsync / hipFreeAsync on `stream`, for the two launches: the one
+ * case in which an entry point of this header allocates at call time.)
+ *
+ * The same post-pass for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc): no counterpart in the reference.  It always runs the two-pass form and keeps the partial maxima in a
+ * 64 KB array that the library holds on every GPU it runs on; it calls no allocating routine.  groups * pieces must
+ * not exceed 16384, pieces = ceil(group_elems / 16384) (pieces of 32768, 65536, .. floats when that is more than 1024;
+ * e.g. one group of 268 M floats, or 16 groups of 16 M), else SED_ERR_CAPACITY; groups <= 65535.  All calls on one GPU
+ * share the array: calls that overlap in time on one GPU (different streams) race; calls of one stream do not. */
+int sed_db_normalize_static(float* x, int64_t groups, int64_t group_elems, int32_t subtract_max, float top_db,
+                            void* stream);
 
 /* ---- decoders -------------------------------------------------------------------------------------- */
 

@@ -60,3 +60,14 @@ clips, lens = sed_amd.cut_events(pcm, 32000, ev, cap=96000)
 us = timeit(lambda: sed_amd.cut_events(pcm, 32000, ev, cap=96000), n=30)
 moved = int(lens.clamp(max=96000).sum().item()) * 4 + clips.numel() * 4
 print(f"{'cut_events 2048 x <= 3 s -> (2048, 96000)':52s} {us:7.1f} us  {moved / us / 1e6:5.2f} TB/s  digest {dig(clips[:64])}")
+# torchlibrosa's top_db: one group = the whole (64, 1, 1001, 64) tensor
+big = -60.0 * torch.rand((64, 1001, 64), generator=g, device=dev)
+def dbn1():
+    t = big.clone()
+    with torch.cuda.device(dev):
+        L.check(L.lib.sed_db_normalize(t.data_ptr(), 1, t.numel(), 0, 80.0, L.stream_ptr(dev)), "db")
+    return t
+t = dbn1()
+us_clone = timeit(lambda: big.clone())
+us = timeit(dbn1)
+print(f"{'sed_db_normalize 1 x (64 * 1001 * 64) (top_db)':52s} {us - us_clone:7.1f} us (clone {us_clone:.1f} subtracted)  {2 * big.numel() * 4 / max(us - us_clone, 1e-3) / 1e6:5.2f} TB/s  digest {dig(t)}")

@@ -885,6 +885,43 @@ __global__ void __launch_bounds__(1024) db_normalize_kernel(float* x, int64_t gr
   }
 }
 
+// The same post-pass for few, large groups (torchlibrosa's top_db clamps against the maximum of the WHOLE tensor): a group
+// is cut into `chunks` pieces of `chunk` floats, one workgroup each.  Pass 1 writes the maximum of every piece to
+// partial[group * chunks + piece]; pass 2 reduces its group's row of partial maxima (they are few) and rewrites its own
+// piece.  max() is exact and order-free, so the result has the bits of the one-workgroup kernel.
+__global__ void __launch_bounds__(256) db_partial_max_kernel(const float* x, int64_t group_elems, int64_t chunk, float* partial) {
+  __shared__ float red[4];
+  const int64_t lo = (int64_t)blockIdx.x * chunk, hi = min(group_elems, lo + chunk);
+  const float* g = x + (int64_t)blockIdx.y * group_elems;
+  float m = -INFINITY;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += 256) m = fmaxf(m, g[i]);
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+__global__ void __launch_bounds__(256) db_apply_kernel(float* x, int64_t group_elems, int64_t chunk, const float* partial,
+                                                       int subtract_max, float top_db) {
+  __shared__ float red[4];
+  const float* row = partial + (int64_t)blockIdx.y * gridDim.x;
+  float m = -INFINITY;
+  for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) m = fmaxf(m, row[i]);
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const float sub = subtract_max ? m : 0.0f;
+  const float floor_v = (top_db >= 0.0f) ? (m - sub) - top_db : -INFINITY;
+  const int64_t lo = (int64_t)blockIdx.x * chunk, hi = min(group_elems, lo + chunk);
+  float* g = x + (int64_t)blockIdx.y * group_elems;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += 256) g[i] = fmaxf(g[i] - sub, floor_v);
+}
+
+// Scratch of sed_db_normalize_static: partial maxima, one float per (group, piece).  Every GPU holds its own copy; the
+// host reaches it through the address hipGetSymbolAddress returns for the current device, never through this name.
+constexpr int kDbStaticFloats = 16384;
+static __device__ __align__(256) float db_static_scratch[kDbStaticFloats];
+
 }  // namespace sed
 
 // ======================================================================================================
@@ -1465,12 +1502,69 @@ extern "C" int sed_mel_from_spectrogram(const sed_plan* pl, const float* spec, i
   return hip_status(hipGetLastError());
 }
 
+// Pieces per group for the two-pass form: about 16 K floats each, at most 1024 per group.
+static inline void db_pieces(int64_t group_elems, int64_t* chunk, int64_t* chunks) {
+  int64_t c = 16384;
+  while ((group_elems + c - 1) / c > 1024) c *= 2;
+  *chunk = c;
+  *chunks = (group_elems + c - 1) / c;
+}
+
+static int db_two_pass(float* x, int64_t groups, int64_t group_elems, int32_t subtract_max, float top_db, float* partial,
+                       hipStream_t stream) {
+  int64_t chunk, chunks;
+  db_pieces(group_elems, &chunk, &chunks);
+  const dim3 grid((unsigned)chunks, (unsigned)groups);
+  hipLaunchKernelGGL(db_partial_max_kernel, grid, dim3(256), 0, stream, x, group_elems, chunk, partial);
+  hipLaunchKernelGGL(db_apply_kernel, grid, dim3(256), 0, stream, x, group_elems, chunk, partial, (int)subtract_max, top_db);
+  return hip_status(hipGetLastError());
+}
+
 extern "C" int sed_db_normalize(float* x, int64_t groups, int64_t group_elems, int32_t subtract_max, float top_db,
                                 void* stream) {
   if (groups < 0 || group_elems < 0 || groups > INT32_MAX) return SED_ERR_BAD_ARG;
   if (groups == 0 || group_elems == 0) return SED_OK;
   if (!x) return SED_ERR_BAD_ARG;
-  hipLaunchKernelGGL(db_normalize_kernel, dim3((unsigned)groups), dim3(1024), 0, (hipStream_t)stream, x, group_elems,
-                     (int)subtract_max, top_db);
-  return hip_status(hipGetLastError());
+  // many groups (a clip each) fill the GPU with one workgroup per group; few large ones are cut into pieces, whose
+  // partial maxima live in a stream-ordered allocation for the duration of the two launches
+  if (groups >= 64 || group_elems <= 65536 || groups > 65535) {
+    hipLaunchKernelGGL(db_normalize_kernel, dim3((unsigned)groups), dim3(1024), 0, (hipStream_t)stream, x, group_elems,
+                       (int)subtract_max, top_db);
+    return hip_status(hipGetLastError());
+  }
+  int64_t chunk, chunks;
+  db_pieces(group_elems, &chunk, &chunks);
+  float* partial = nullptr;
+  SED_HIP_TRY(hipMallocAsync((void**)&partial, (size_t)(groups * chunks) * sizeof(float), (hipStream_t)stream));
+  const int rc = db_two_pass(x, groups, group_elems, subtract_max, top_db, partial, (hipStream_t)stream);
+  const hipError_t fe = hipFreeAsync(partial, (hipStream_t)stream);
+  return rc ? rc : hip_status(fe);
+}
+
+extern "C" int sed_db_normalize_static(float* x, int64_t groups, int64_t group_elems, int32_t subtract_max, float top_db,
+                                       void* stream) {
+  if (groups < 0 || group_elems < 0) return SED_ERR_BAD_ARG;
+  if (groups == 0 || group_elems == 0) return SED_OK;
+  if (!x) return SED_ERR_BAD_ARG;
+  int64_t chunk, chunks;
+  db_pieces(group_elems, &chunk, &chunks);
+  if (groups > 65535 || groups * chunks > kDbStaticFloats) return SED_ERR_CAPACITY;
+  // the scratch array's address on the current device, looked up once per device
+  static std::mutex mu;
+  static float* ptr_of[16] = {};
+  int dev = -1;
+  SED_HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 16) return SED_ERR_BAD_ARG;
+  float* partial = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    if (!ptr_of[dev]) {
+      float* p = nullptr;
+      SED_HIP_TRY(hipGetSymbolAddress((void**)&p, HIP_SYMBOL(db_static_scratch)));
+      ptr_of[dev] = p;
+    }
+    partial = ptr_of[dev];
+  }
+  // every piece's slot is written by pass 1 before pass 2 reads it: nothing has to start at zero
+  return db_two_pass(x, groups, group_elems, subtract_max, top_db, partial, (hipStream_t)stream);
 }

@@ -65,6 +65,7 @@ SIGNATURES = {
     "sed_spectrogram_forward": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp]),
     "sed_mel_from_spectrogram": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "sed_db_normalize": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _vp]),
+    "sed_db_normalize_static": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _vp]),
     "sed_threshold_runs": (C.c_int, [_vp, _i64, _i64, _i64, _f32, _i32, _vp, _vp, _i32, _vp]),
     "sed_activity_edges": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i32, _vp]),
     "sed_argmax_runs": (C.c_int, [_vp, _i64, _i64, _i64, _i32, _i32, _vp, _vp, _i32, _vp]),
