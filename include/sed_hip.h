@@ -218,8 +218,8 @@ int sed_merge_runs(const int32_t* runs, const int32_t* counts, int64_t n_groups,
 
 /* sed_threshold_runs followed by sed_merge_runs in one launch (the detector decode of yamnet_train.py:55-71, then
  * the gap merge of merge_events.py:36-55, per stream and class): packed int32 [B*C][1 + 2*cap] holds, per trace,
- * the merged count and then its (start, end) frame pairs.  cap >= T/2 + 1 and cap <= 256 (the raw runs of a trace
- * stay in LDS), else SED_ERR_CAPACITY. */
+ * the merged count and then its (start, end) frame pairs.  cap >= T/2 + 1 (a trace of T frames has at most that many
+ * runs) and T <= 8190 (the raw runs of a trace stay in LDS, sized per launch for T), else SED_ERR_CAPACITY. */
 int sed_threshold_merge_runs(const float* probs, int64_t B, int64_t T, int64_t C, float threshold, int32_t smoothing,
                              const double* time_table, int32_t table_len, double gap, int32_t* packed, int32_t cap,
                              void* stream);
@@ -239,7 +239,8 @@ int sed_pack_events(const int32_t* runs, int64_t runs_stride, const int32_t* cou
 /* sed_threshold_merge_runs followed by sed_pack_events in one launch, with the same records as the two calls give
  * (detector decode of src/models/yamnet_train.py:55-71, gap merge of src/utils/merge_events.py:36-55, record order of
  * src/models/crnn/utils.py:99-134): probs fp32 [B][T][C] -> records int32 [B][cap_out + 1][4] as sed_pack_events
- * lays them out.  T/2 + 1 <= 256 (the raw runs of a trace stay in LDS), else SED_ERR_CAPACITY. */
+ * lays them out.  T <= 8190 (the raw and merged runs of a trace stay in LDS, sized per launch for T: 862-frame CRNN
+ * traces and 4096-frame HTS-AT framewise maps fit), else SED_ERR_CAPACITY. */
 int sed_threshold_merge_records(const float* probs, int64_t B, int64_t T, int64_t C, float threshold, int32_t smoothing,
                                 const double* time_table, int32_t table_len, double gap, int32_t first_stream,
                                 int32_t* records, int32_t cap_out, void* stream);

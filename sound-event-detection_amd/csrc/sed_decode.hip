@@ -5,6 +5,7 @@
 // depend on scheduling.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 
 // The fp64 smoothing and the gap compare must round exactly like the CPU code they mirror: no fused
@@ -282,22 +283,27 @@ __global__ void __launch_bounds__(256) merge_kernel(const double* onsets, const 
 
 // Threshold -> runs -> gap merge -> packed record in one launch: the raw runs of a trace stay in LDS.
 // packed[trace] = (count, start_0, end_0, start_1, end_1, ...), 1 + 2*cap ints per trace.
-constexpr int kFusedCap = 256;  // raw runs per trace the LDS buffer holds (T <= 2*kFusedCap - 2)
+// The LDS buffers are sized by the host for the trace length: kcap = T/2 + 1 run slots per wavefront (a trace of T
+// frames has at most that many runs), as many wavefronts per workgroup (1..4) as 64 KB of LDS hold.
+constexpr int kFusedMaxCap = 4096;     // run slots of the longest trace the fused kernels take: T <= 8190 frames
+constexpr int kFusedLdsBytes = 65536;  // LDS a workgroup of the fused kernels may use
 __global__ void __launch_bounds__(256) threshold_merge_kernel(const float* probs, int64_t n_traces, int T, int C,
                                                               float thr, int smoothing, const double* table,
-                                                              int table_len, double gap, int32_t* packed, int cap) {
-  __shared__ int32_t raw[4][2 * kFusedCap];
+                                                              int table_len, double gap, int32_t* packed, int cap,
+                                                              int kcap) {
+  extern __shared__ int32_t fused_lds[];  // [wavefront][2 * kcap] raw runs
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int64_t trace = (int64_t)blockIdx.x * 4 + w;
+  const int64_t trace = (int64_t)blockIdx.x * (blockDim.x >> 6) + w;
   if (trace >= n_traces) return;
+  int32_t* raw = fused_lds + (size_t)w * 2 * kcap;
   const int64_t b = trace / C;
   const int c = (int)(trace - b * C);
-  const int n = threshold_runs_wave(probs + b * (int64_t)T * C + c, T, C, thr, smoothing, raw[w], cap, lane);
+  const int n = threshold_runs_wave(probs + b * (int64_t)T * C + c, T, C, thr, smoothing, raw, kcap, lane);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   int32_t* rec = packed + trace * (int64_t)(1 + 2 * cap);
-  const int n_out = merge_wave<true>(nullptr, nullptr, raw[w], 0, min(n, cap), table, table_len, gap, nullptr, nullptr,
+  const int n_out = merge_wave<true>(nullptr, nullptr, raw, 0, min(n, kcap), table, table_len, gap, nullptr, nullptr,
                                      rec + 1, 0, lane);
   if (lane == 0) rec[0] = n_out;
 }
@@ -332,26 +338,27 @@ __global__ void __launch_bounds__(256) pack_events_kernel(const int32_t* runs, i
 __global__ void __launch_bounds__(256) threshold_merge_records_kernel(const float* probs, int64_t n_streams, int T, int C,
                                                                       float thr, int smoothing, const double* table,
                                                                       int table_len, double gap, int first_stream,
-                                                                      int32_t* records, int cap_out) {
-  __shared__ int32_t raw[4][2 * kFusedCap];
-  __shared__ int32_t merged[4][2 * kFusedCap];
+                                                                      int32_t* records, int cap_out, int kcap) {
+  extern __shared__ int32_t fused_lds[];  // [wavefront][raw runs 2 * kcap | merged runs 2 * kcap]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int64_t s = (int64_t)blockIdx.x * 4 + w;
+  const int64_t s = (int64_t)blockIdx.x * (blockDim.x >> 6) + w;
   if (s >= n_streams) return;
+  int32_t* raw = fused_lds + (size_t)w * 4 * kcap;
+  int32_t* merged = raw + 2 * kcap;
   int4* rec = reinterpret_cast<int4*>(records) + s * (int64_t)(cap_out + 1);
   int base = 0;
   for (int c = 0; c < C; ++c) {
-    const int n = threshold_runs_wave(probs + s * (int64_t)T * C + c, T, C, thr, smoothing, raw[w], kFusedCap, lane);
+    const int n = threshold_runs_wave(probs + s * (int64_t)T * C + c, T, C, thr, smoothing, raw, kcap, lane);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int n_out = merge_wave<true>(nullptr, nullptr, raw[w], 0, min(n, kFusedCap), table, table_len, gap, nullptr,
-                                       nullptr, merged[w], 0, lane);
+    const int n_out = merge_wave<true>(nullptr, nullptr, raw, 0, min(n, kcap), table, table_len, gap, nullptr,
+                                       nullptr, merged, 0, lane);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     for (int k = lane; k < n_out && base + k < cap_out; k += 64)
-      rec[1 + base + k] = make_int4((int)s + first_stream, c, merged[w][2 * k], merged[w][2 * k + 1]);
+      rec[1 + base + k] = make_int4((int)s + first_stream, c, merged[2 * k], merged[2 * k + 1]);
     base += n_out;
     __builtin_amdgcn_wave_barrier();  // the next class overwrites both buffers
   }
@@ -366,6 +373,13 @@ using namespace sed;
 
 static inline int hip_status(hipError_t e) { return e == hipSuccess ? SED_OK : SED_ERR_HIP - (int)e; }
 static inline unsigned blocks_for(int64_t waves) { return (unsigned)((waves + 3) / 4); }
+// Launch shape of the fused decoders: run slots per wavefront for traces of T frames, wavefronts per workgroup that
+// `bytes_per_slot` bytes of LDS per slot allow (0: the trace is too long for the LDS buffers).
+static inline int fused_waves(int64_t T, int bytes_per_slot, int* kcap) {
+  *kcap = (int)std::max<int64_t>(256, T / 2 + 1);
+  if (*kcap > kFusedMaxCap) return 0;
+  return std::max(1, std::min(4, kFusedLdsBytes / (bytes_per_slot * *kcap)));
+}
 
 extern "C" int sed_threshold_runs(const float* probs, int64_t B, int64_t T, int64_t C, float threshold,
                                   int32_t smoothing, int32_t* runs, int32_t* counts, int32_t cap, void* stream) {
@@ -440,11 +454,14 @@ extern "C" int sed_threshold_merge_runs(const float* probs, int64_t B, int64_t T
                                         int32_t* packed, int32_t cap, void* stream) {
   if (B < 0 || T < 0 || C < 0 || cap < 1 || smoothing < 0 || smoothing > 2 || table_len < 1) return SED_ERR_BAD_ARG;
   if (T >= INT32_MAX - 64 || C > INT32_MAX || B * C > (int64_t)INT32_MAX * 4) return SED_ERR_BAD_ARG;
-  if (cap > kFusedCap || T / 2 + 1 > cap) return SED_ERR_CAPACITY;  // every raw run must fit the LDS buffer
+  int kcap;
+  const int waves = fused_waves(T, 8, &kcap);
+  if (!waves || T / 2 + 1 > cap) return SED_ERR_CAPACITY;  // every raw run must fit the LDS buffer and the record
   if (B * C == 0) return SED_OK;
   if (!packed || !time_table || (T > 0 && !probs)) return SED_ERR_BAD_ARG;
-  hipLaunchKernelGGL(threshold_merge_kernel, dim3(blocks_for(B * C)), dim3(256), 0, (hipStream_t)stream, probs, B * C,
-                     (int)T, (int)C, threshold, (int)smoothing, time_table, (int)table_len, gap, packed, (int)cap);
+  hipLaunchKernelGGL(threshold_merge_kernel, dim3((unsigned)((B * C + waves - 1) / waves)), dim3(64 * waves),
+                     (size_t)waves * 8 * kcap, (hipStream_t)stream, probs, B * C, (int)T, (int)C, threshold, (int)smoothing,
+                     time_table, (int)table_len, gap, packed, (int)cap, kcap);
   return hip_status(hipGetLastError());
 }
 
@@ -453,12 +470,14 @@ extern "C" int sed_threshold_merge_records(const float* probs, int64_t B, int64_
                                            int32_t first_stream, int32_t* records, int32_t cap_out, void* stream) {
   if (B < 0 || T < 0 || C < 0 || cap_out < 1 || smoothing < 0 || smoothing > 2 || table_len < 1) return SED_ERR_BAD_ARG;
   if (T >= INT32_MAX - 64 || C > INT32_MAX || B + (int64_t)first_stream > INT32_MAX) return SED_ERR_BAD_ARG;
-  if (T / 2 + 1 > kFusedCap) return SED_ERR_CAPACITY;  // every raw run of a trace must fit the LDS buffer
+  int kcap;
+  const int waves = fused_waves(T, 16, &kcap);
+  if (!waves) return SED_ERR_CAPACITY;  // every raw run of a trace must fit the LDS buffer
   if (B == 0) return SED_OK;
   if (!records || !time_table || (T > 0 && C > 0 && !probs)) return SED_ERR_BAD_ARG;
-  hipLaunchKernelGGL(threshold_merge_records_kernel, dim3(blocks_for(B)), dim3(256), 0, (hipStream_t)stream, probs, B,
-                     (int)T, (int)C, threshold, (int)smoothing, time_table, (int)table_len, gap, (int)first_stream, records,
-                     (int)cap_out);
+  hipLaunchKernelGGL(threshold_merge_records_kernel, dim3((unsigned)((B + waves - 1) / waves)), dim3(64 * waves),
+                     (size_t)waves * 16 * kcap, (hipStream_t)stream, probs, B, (int)T, (int)C, threshold, (int)smoothing,
+                     time_table, (int)table_len, gap, (int)first_stream, records, (int)cap_out, kcap);
   return hip_status(hipGetLastError());
 }
 

@@ -227,7 +227,11 @@ __device__ __forceinline__ void stage_span_dma(const FrontParams& p, float* dst,
 template <class G, int HOP, int SKEW>
 __device__ __forceinline__ void stage_span_dma_skewed(const FrontParams& p, float* dst, int64_t b, int64_t s0, int lane) {
   constexpr int SPAN = (G::FPW - 1) * HOP + G::NFFT;
+#ifdef SED_SPAN_HOPS  // timing experiments: fetch only the first hops of the span (results are then garbage)
+  constexpr int HOPS = SED_SPAN_HOPS;
+#else
   constexpr int HOPS = (SPAN + HOP - 1) / HOP;
+#endif
   static_assert(HOP % 64 == 0 && SPAN % 64 == 0 && HOP * 4 * 3 + 4096 > 0, "whole 64-sample pieces");
   const float* src = (const float*)p.pcm + b * p.pcm_stride + s0;
   static_for<0, (HOPS + 2) / 3>([&](auto Tf) {

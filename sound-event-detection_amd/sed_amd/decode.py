@@ -31,6 +31,23 @@ NON_EVENT_LABEL = "non_event"                                               # sr
 _SMOOTH = {None: L.SMOOTH_NONE, "none": L.SMOOTH_NONE, "median3": L.SMOOTH_MEDIAN3, "gauss": L.SMOOTH_GAUSS25}
 
 
+def _smooth_code(smoothing) -> int:
+    try:
+        return _SMOOTH[smoothing]
+    except (KeyError, TypeError):
+        raise ValueError(f"smoothing must be one of None, 'none', 'median3', 'gauss', not {smoothing!r}") from None
+
+
+def _check_table(time_table, device) -> None:
+    """The kernels read the time table as a contiguous device array of fp64 on the device of the data."""
+    if not torch.is_tensor(time_table) or time_table.dtype != torch.float64:
+        raise TypeError("time_table must be a torch.float64 tensor")
+    if time_table.device != device:
+        raise ValueError(f"time_table is on {time_table.device}, the data on {device}")
+    if time_table.dim() != 1 or not time_table.is_contiguous() or time_table.numel() < 1:
+        raise ValueError("time_table must be a contiguous 1-D tensor with at least one entry")
+
+
 def _device() -> torch.device:
     if not torch.cuda.is_available():
         raise RuntimeError("no ROCm device is visible; the decoders have no CPU path")
@@ -54,7 +71,7 @@ def threshold_runs(probs: torch.Tensor, threshold: float, smoothing=None):
     runs = torch.empty((B, Cn, cap, 2), dtype=torch.int32, device=probs.device)
     counts = torch.empty((B, Cn), dtype=torch.int32, device=probs.device)   # the kernel writes every count
     with torch.cuda.device(probs.device):
-        L.check(L.lib.sed_threshold_runs(probs.data_ptr(), B, T, Cn, float(np.float32(threshold)), _SMOOTH[smoothing],
+        L.check(L.lib.sed_threshold_runs(probs.data_ptr(), B, T, Cn, float(np.float32(threshold)), _smooth_code(smoothing),
                                          runs.data_ptr(), counts.data_ptr(), cap, L.stream_ptr(probs.device)),
                 "sed_threshold_runs")
     return runs, counts
@@ -81,7 +98,7 @@ def argmax_runs(probs: torch.Tensor, smoothing=None, drop_last_classes: int = 0)
     runs = torch.empty((B, cap, 3), dtype=torch.int32, device=probs.device)
     counts = torch.zeros((B,), dtype=torch.int32, device=probs.device)
     with torch.cuda.device(probs.device):
-        L.check(L.lib.sed_argmax_runs(probs.data_ptr(), B, T, Cn, _SMOOTH[smoothing], drop_last_classes,
+        L.check(L.lib.sed_argmax_runs(probs.data_ptr(), B, T, Cn, _smooth_code(smoothing), drop_last_classes,
                                       runs.data_ptr(), counts.data_ptr(), cap, L.stream_ptr(probs.device)),
                 "sed_argmax_runs")
     return runs, counts
@@ -98,6 +115,10 @@ def argmax_histogram(probs: torch.Tensor, drop_last_classes: int = 0) -> torch.T
 
 def merge_runs(runs: torch.Tensor, counts: torch.Tensor, time_table: torch.Tensor, gap: float):
     """Gap-merge frame-index runs (.., cap, 2) group by group using fp64 times time_table[frame]."""
+    _check_table(time_table, runs.device)
+    if runs.dtype != torch.int32 or counts.dtype != torch.int32 or counts.device != runs.device:
+        raise TypeError("runs and counts must be int32 tensors on one device")
+    runs, counts = runs.contiguous(), counts.contiguous()
     cap = runs.shape[-2]
     n_groups = counts.numel()
     out_runs = torch.empty_like(runs)
@@ -111,13 +132,17 @@ def merge_runs(runs: torch.Tensor, counts: torch.Tensor, time_table: torch.Tenso
 
 def threshold_merge_runs(probs: torch.Tensor, threshold: float, time_table: torch.Tensor, gap: float, smoothing=None):
     """threshold_runs + merge_runs in one launch: probs (B, T, C) -> packed int32 (B, C, 1 + 2*cap), cap = T//2 + 1;
-    packed[b, c, 0] = merged count, then (start, end) frame pairs.  T <= 510 (longer traces: the two-step path)."""
+    packed[b, c, 0] = merged count, then (start, end) frame pairs.  T <= 8190."""
+    if not probs.is_cuda or probs.dim() != 3 or probs.dtype != torch.float32:
+        raise ValueError("probs must be an fp32 (B, T, C) tensor on a ROCm device")
+    _check_table(time_table, probs.device)
+    probs = probs.contiguous()
     B, T, Cn = probs.shape
     cap = T // 2 + 1
     packed = torch.empty((B, Cn, 1 + 2 * cap), dtype=torch.int32, device=probs.device)
     with torch.cuda.device(probs.device):
         L.check(L.lib.sed_threshold_merge_runs(probs.data_ptr(), B, T, Cn, float(np.float32(threshold)),
-                                               _SMOOTH[smoothing], time_table.data_ptr(), time_table.numel(),
+                                               _smooth_code(smoothing), time_table.data_ptr(), time_table.numel(),
                                                float(gap), packed.data_ptr(), cap, L.stream_ptr(probs.device)),
                 "sed_threshold_merge_runs")
     return packed
@@ -132,12 +157,13 @@ def threshold_merge_records(probs: torch.Tensor, threshold: float, time_table: t
         raise RuntimeError("threshold_merge_records needs device tensors (there is no CPU path)")
     if probs.dim() != 3 or probs.dtype != torch.float32:
         raise ValueError("probs must be fp32 (S, T, C)")
+    _check_table(time_table, probs.device)
     probs = probs.contiguous()
     S, T, Cn = probs.shape
     records = torch.empty((S, cap + 1, 4), dtype=torch.int32, device=probs.device)
     with torch.cuda.device(probs.device):
         L.check(L.lib.sed_threshold_merge_records(probs.data_ptr(), S, T, Cn, float(np.float32(threshold)),
-                                                  _SMOOTH[smoothing], time_table.data_ptr(), time_table.numel(),
+                                                  _smooth_code(smoothing), time_table.data_ptr(), time_table.numel(),
                                                   float(gap), int(first_stream), records.data_ptr(), int(cap),
                                                   L.stream_ptr(probs.device)), "sed_threshold_merge_records")
     return records

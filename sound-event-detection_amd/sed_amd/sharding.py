@@ -77,8 +77,8 @@ def decode_and_exchange(det_probs: torch.Tensor, time_table: torch.Tensor, gap: 
     """The detector-side tail of one batch on one rank, all on the device and without host synchronisation:
     smoothing + threshold + run extraction + gap merge (src/models/yamnet_train.py:55-71, src/utils/merge_events.py:36-55)
     of this rank's streams and their (stream, class, onset, offset) records in one launch, then the all-gather of the
-    record buffers.  det_probs (S, T, C) fp32 on the device, T <= 510 (longer traces: threshold_runs + merge_runs +
-    pack_events); returns what all_gather_events returns.
+    record buffers.  det_probs (S, T, C) fp32 on the device, T <= 8190 (covers the 862-frame CRNN traces of
+    src/models/crnn/crnn.py:181-182 and HTS-AT's 4096-frame maps); returns what all_gather_events returns.
     host_staging copies the records to the host before the collective (for backends without a device path)."""
     from . import decode as D
     records = D.threshold_merge_records(det_probs, threshold, time_table, gap, smoothing, cap, first_stream)

@@ -239,7 +239,9 @@ def test_fused_threshold_merge_equals_two_launches():
     dev = torch.device("cuda", 0)
     for (B, T, C), smooth, gap, step in (((256, 20, 1), "median3", 0.6, 0.48), ((33, 41, 6), "median3", 0.3, 0.48),
                                          ((16, 500, 5), "gauss", 1.0, 1024 / 44100), ((5, 1, 2), None, 0.6, 0.48),
-                                         ((7, 64, 3), None, 0.6, 0.1), ((3, 129, 4), "median3", 0.0, 0.25)):
+                                         ((7, 64, 3), None, 0.6, 0.1), ((3, 129, 4), "median3", 0.0, 0.25),
+                                         ((6, 862, 5), "gauss", 0.3, 1024 / 44100), ((2, 4096, 6), "gauss", 0.05, 20.0 / 4096),
+                                         ((3, 8190, 1), None, 0.01, 0.01), ((2, 511, 2), None, 0.0, 1.0)):
         probs = torch.from_numpy(rng.random((B, T, C)).astype(np.float32)).to(dev)
         probs[0] = 1.0                                                  # one fully active stream
         probs[-1] = 0.0                                                 # one silent stream
@@ -255,7 +257,20 @@ def test_fused_threshold_merge_equals_two_launches():
                 n = mcounts[b, c]
                 assert np.array_equal(packed[b, c, 1:1 + 2 * n].reshape(n, 2), mruns[b, c, :n]), (B, T, C, b, c)
     with pytest.raises(ValueError):
-        D.threshold_merge_runs(torch.zeros((1, 600, 1), device=dev), 0.5, table, 0.6)   # beyond the LDS capacity
+        D.threshold_merge_runs(torch.zeros((1, 8192, 1), device=dev), 0.5, table, 0.6)  # beyond the LDS capacity
+    # the kernels read the time table as fp64 on the device of the data: anything else is refused before the launch
+    p1 = torch.zeros((1, 8, 1), device=dev)
+    good = torch.zeros(10, dtype=torch.float64, device=dev)
+    for bad, exc in ((good.float(), TypeError), (good.cpu(), ValueError), (torch.zeros(20, dtype=torch.float64, device=dev)[::2], ValueError),
+                     ([0.0] * 10, TypeError)):
+        with pytest.raises(exc):
+            D.threshold_merge_runs(p1, 0.5, bad, 0.6)
+        with pytest.raises(exc):
+            D.threshold_merge_records(p1, 0.5, bad, 0.6)
+        with pytest.raises(exc):
+            D.merge_runs(*D.threshold_runs(p1, 0.5), bad, 0.6)
+    with pytest.raises(ValueError):
+        D.threshold_merge_records(p1, 0.5, good, 0.6, smoothing="gaussian")
 
 
 def test_framewise_interpolate_and_pad():

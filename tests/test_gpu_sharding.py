@@ -91,7 +91,9 @@ def test_records_in_one_launch_equal_the_two_step_path():
     dev = _dev()
     rng = np.random.default_rng(23)
     for (S, T, C, cap, gap, smoothing) in ((37, 20, 1, 16, 0.6, "median3"), (9, 41, 6, 5, 1.0, None), (130, 96, 5, 16, 0.3, "median3"),
-                                           (1, 3, 2, 1, 0.6, None), (5, 510, 3, 64, 0.5, "gauss"), (3, 1, 1, 4, 0.6, "median3")):
+                                           (1, 3, 2, 1, 0.6, None), (5, 510, 3, 64, 0.5, "gauss"), (3, 1, 1, 4, 0.6, "median3"),
+                                           (4, 862, 5, 64, 0.3, "gauss"), (3, 4096, 6, 300, 0.05, "median3"),
+                                           (2, 8190, 2, 4200, 0.0, None), (3, 513, 2, 300, 0.5, None)):
         probs = rng.random((S, T, C), dtype=np.float32)
         probs[0] = 0.0
         if S > 2:
@@ -118,10 +120,51 @@ def test_records_in_one_launch_equal_the_two_step_path():
                     for k, m in enumerate(merged):
                         runs[s_, c, k] = (table_host.index(m["event_onset"]), table_host.index(m["event_offset"]))
             assert np.array_equal(got.cpu().numpy(), od.pack_events(runs, counts, cap, first_stream=700)), (S, T, C, cap)
-    with pytest.raises(ValueError):                                    # 512 frames: one raw run too many for the LDS buffer
-        D.threshold_merge_records(torch.zeros((1, 512, 1), device=dev), 0.5, torch.zeros(514, dtype=torch.float64, device=dev), 0.5)
+    with pytest.raises(ValueError):                                    # 8192 frames: one raw run too many for the LDS buffer
+        D.threshold_merge_records(torch.zeros((1, 8192, 1), device=dev), 0.5, torch.zeros(8194, dtype=torch.float64, device=dev), 0.5)
     with pytest.raises(RuntimeError):
         D.threshold_merge_records(torch.zeros((1, 4, 1)), 0.5, torch.zeros(6, dtype=torch.float64), 0.5)
+
+
+def test_decode_and_exchange_crnn_traces_against_the_oracle_chain():
+    """decode_and_exchange on CRNN-shaped probabilities (500 files x 862 frames x 5 classes, src/models/crnn/crnn.py:181-182):
+    gaussian smoothing + threshold (crnn.py:418-425), region decode with round(k / fps, 3) times (crnn/utils.py:91-134) and
+    the gap merge (src/utils/merge_events.py:4-60) at the three gaps of the reference's result files, against the oracle's
+    chain of the same steps, as (stream, class, onset frame, offset frame) records."""
+    import sed_amd
+    dev = _dev()
+    rng = np.random.default_rng(418)
+    S, T, C, fps = 500, 862, 5, 44100 / 1024
+    # smoothed noise through a sigmoid: a few events per class and file, like the reference's result files
+    z = rng.standard_normal((S, T + 40, C)).astype(np.float32)
+    z = np.stack([np.convolve(z[s, :, c], np.ones(41, np.float32) / 6.0, mode="valid") for s in range(S) for c in range(C)])
+    probs = np.ascontiguousarray((1.0 / (1.0 + np.exp(-1.5 * z))).astype(np.float32).reshape(S, C, T).transpose(0, 2, 1))
+    probs[3] = 1.0
+    probs[4] = 0.0
+    labels = {0: "car_horn", 1: "cough", 2: "dog_bark", 3: "siren", 4: "gun_shot"}
+    files = [f"f{i}.wav" for i in range(S)]
+    table_host = [round(np.int64(k) * (1.0 / fps), 3) for k in range(T + 2)]
+    frame_of = {t: k for k, t in enumerate(table_host)}
+    assert len(frame_of) == len(table_host)
+    table = torch.tensor(table_host, dtype=torch.float64, device=dev)
+    raw = od.decode_predictions(od.smooth_and_threshold(probs), files, labels, fps)
+    class_of = {v: k for k, v in labels.items()}
+    pt = torch.from_numpy(probs).to(dev)
+    n_events = 0
+    for gap in (0.3, 0.6, 1.0):
+        cap = 64
+        got = sed_amd.sharding.decode_and_exchange(pt, table, gap, cap=cap, first_stream=0, threshold=0.5, smoothing="gauss")
+        got = got.cpu().numpy()
+        assert got.shape == (S, cap + 1, 4)
+        for i, f in enumerate(files):
+            merged = od.merge_close_events(raw[f], gap)
+            # records are class-major and onset-ascending; the reference's merged list is onset-sorted across classes
+            want = sorted((class_of[e["event_label"]], frame_of[e["event_onset"]], frame_of[e["event_offset"]]) for e in merged)
+            n = got[i, 0, 0]
+            assert got[i, 0, 1] == 0 and n == len(want), (gap, f)
+            assert [tuple(r[1:]) for r in got[i, 1:1 + n]] == want and np.all(got[i, 1:1 + n, 0] == i), (gap, f)
+            n_events += n
+    assert n_events > 3 * S
 
 
 def test_exchange_over_rccl_one_rank_group(rccl_group):
