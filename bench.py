@@ -13,6 +13,12 @@ with the next step).  Everything in the step stays on the device; formatting eve
 it and is timed separately ("decode_with_host_formatting_ms").  Ranks own independent streams (weak scaling).
 Rank 0 prints one JSON line.
 
+`--workload yamnet` and `--workload crnn_chain` time the other single-GPU configurations BASELINE.json names (one JSON
+line each, N = 1 only): the YAMNet feature front-end on 64 and 512 clips of 10 s at 16 kHz (configs[0]) beside its CPU
+formulation, and the CRNN decode chain on 500 files x 862 frames x 5 classes (configs[2]): gaussian smoothing, threshold,
+region decode and the 0.3 / 0.6 / 1.0 s gap merges INCLUDING the host formatting of the event dictionaries, beside the
+pure-Python formulation of the reference on the host.  The default line is unchanged by them.
+
 `--gpus N` without a torchrun environment starts the N ranks itself (python -m torch.distributed.run as a child
 process, before this process touches the GPU) and relays rank 0's line.
 """
@@ -37,28 +43,227 @@ HBM_PEAK_GBS = 8000.0
 PREWARM_S = 0.3
 
 
-def synth_pcm(n_clips, n_samples, device, seed):
+def synth_pcm(n_clips, n_samples, device, seed, sr=SR):
     """Seeded synthetic audio generated on the device: noise + two sine bursts per clip + 0.5 s of silence."""
     g = torch.Generator(device=device).manual_seed(seed)
     x = 0.1 * torch.randn((n_clips, n_samples), generator=g, device=device)
-    t = torch.arange(n_samples, device=device) / SR
+    t = torch.arange(n_samples, device=device) / sr
     f = 200.0 + 5800.0 * torch.rand((n_clips, 2), generator=g, device=device)
     a = 0.05 + 0.45 * torch.rand((n_clips, 2), generator=g, device=device)
     s0 = torch.rand((n_clips, 2), generator=g, device=device) * (CLIP_S - 3.0)
     for j in range(2):
         m = (t[None] >= s0[:, j:j + 1]) & (t[None] < s0[:, j:j + 1] + 2.0)
         x += m * a[:, j:j + 1] * torch.sin(2 * torch.pi * f[:, j:j + 1] * t[None])
-    sil = (torch.rand((n_clips, 1), generator=g, device=device) * (CLIP_S - 0.5) * SR).long()
+    sil = (torch.rand((n_clips, 1), generator=g, device=device) * (CLIP_S - 0.5) * sr).long()
     idx = torch.arange(n_samples, device=device)[None]
-    x.masked_fill_((idx >= sil) & (idx < sil + SR // 2), 0.0)
+    x.masked_fill_((idx >= sil) & (idx < sil + sr // 2), 0.0)
     return x.clamp_(-1.0, 1.0).contiguous()
+
+
+def cpu_model_name():
+    try:
+        with open("/proc/cpuinfo") as f:
+            return next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "")
+    except OSError:
+        return ""
+
+
+def measure_h2d(x):
+    """Pinned host -> device copy of the batch, fp32 and int16, outside the timed region (the step's inputs are resident
+    in HBM; a caller that hands over host PCM pays this on top).  Best of three copies each, HIP events."""
+    out = {}
+    for name, dtype in (("f32", torch.float32), ("i16", torch.int16)):
+        host = torch.empty(x.shape, dtype=dtype, pin_memory=True)
+        host.zero_()
+        dst = torch.empty(x.shape, dtype=dtype, device=x.device)
+        best = None
+        for _ in range(4):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            dst.copy_(host, non_blocking=True)
+            e1.record()
+            e1.synchronize()
+            ms = e0.elapsed_time(e1)
+            best = ms if best is None else min(best, ms)
+        out[name] = best
+        out[name + "_GBps"] = host.numel() * host.element_size() / (best * 1e-3) / 1e9
+        del host, dst
+    out["note"] = "pinned host -> device copy of the 256-clip batch, best of 4, not part of any timed step"
+    return out
+
+
+def time_kernel(fn, steps, warmup):
+    """Mean and percentiles of one launch timed with HIP events on the current stream, after `warmup` untimed calls."""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    ms = sorted(a.elapsed_time(b) for a, b in ev)
+    return sum(ms) / len(ms), [ms[int(q * (len(ms) - 1))] for q in (0.1, 0.5, 0.9)], wall
+
+
+def bench_yamnet(args):
+    """BASELINE.json configs[0]: YAMNet features (16 kHz, 400/160/512, 64 HTK mel, ln(x + 0.001)) on 64 clips of 10 s,
+    and on the 512-clip shard of the stream server; the CPU line is the TensorFlow formulation of the same features
+    (frame, Hann, rFFT 512, magnitude, mel matmul, log) on torch's CPU kernels."""
+    import sed_amd
+    dev = torch.device("cuda", 0)
+    sr, L = 16000, 160000
+    fe = sed_amd.LogMelFrontend(sed_amd.FrontendConfig.yamnet(), layout="btm")
+    t_pre = time.perf_counter()
+    xs = {B: synth_pcm(B, L, dev, 77 + B, sr=sr) for B in (64, 512)}
+    while time.perf_counter() - t_pre < PREWARM_S:
+        fe(xs[512])
+        torch.cuda.synchronize()
+    rows = {}
+    for B, x in xs.items():
+        T = fe.num_frames(L, dev)
+        kern_ms, pcts, wall = time_kernel(lambda: fe(x), args.steps, args.warmup)
+        alg = B * (L * 4 + T * 64 * 4)
+        rows[B] = {"clips": B, "frames_per_clip": T, "kernel_ms": kern_ms, "kernel_ms_p10_p50_p90": pcts,
+                   "ms_per_step": wall / args.steps * 1e3, "audio_hours_per_s": B * 10 / 3600.0 / (wall / args.steps),
+                   "algorithmic_bytes_per_launch": alg, "achieved_GBps": alg / (kern_ms * 1e-3) / 1e9}
+    big = rows[512]
+    res = {"metric": "log-mel audio-hours/sec", "value": big["audio_hours_per_s"], "unit": "audio-hours/s", "n_gpus": 1,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": big["ms_per_step"], "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "YAMNet feature front-end 16 kHz 25/10 ms 64 mel, 10 s clips (BASELINE.json configs[0]); value "
+                                  "is the 512-clip shard of the stream server, the 64-clip batch of configs[0] is in batches",
+                      "batches": [rows[64], rows[512]], "pcm": "f32", "parallelism": "1 GPU"},
+           "roofline": {"bound": "hbm", "kernel": "stft_mel_kernel<n_fft=512, magnitude, mel+log>", "achieved": big["achieved_GBps"],
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": big["achieved_GBps"] / HBM_PEAK_GBS, "traffic": None,
+                        "algorithmic_bytes_per_launch": big["algorithmic_bytes_per_launch"], "kernel_ms": big["kernel_ms"]}}
+    if not args.no_cpu_baseline:
+        from oracle.cpu_baseline import YamnetCpuFrontend, time_cpu_frontend
+        sample = xs[64].cpu()
+        threads = torch.get_num_threads()
+        v, el, n = time_cpu_frontend(YamnetCpuFrontend(), sample, sr, budget_s=10.0)
+        torch.set_num_threads(1)
+        v1, el1, n1 = time_cpu_frontend(YamnetCpuFrontend(), sample[:8], sr, budget_s=5.0)
+        torch.set_num_threads(threads)
+        res["cpu_baseline"] = {"value": v, "unit": "audio-hours/s", "cores": threads, "kind": "port",
+                               "sample": f"{n} passes over the 64 clips of configs[0] (10 s each), {el:.1f} s of CPU work, TensorFlow "
+                                         "formulation (frame, Hann, rFFT 512, magnitude, mel matmul, log) on torch CPU",
+                               "single_thread_value": v1, "host_cpus": os.cpu_count(), "cpu_model": cpu_model_name()}
+    return res
+
+
+def crnn_probabilities(n_files, n_frames, n_classes, seed):
+    """Sigmoid of smoothed noise with about 18 events per file, the density of the reference's crnn_results.json."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    z = rng.standard_normal((n_files * n_classes, n_frames + 140)).astype(np.float32)
+    k = np.hanning(141).astype(np.float32)
+    z = np.stack([np.convolve(r, k / np.sqrt((k * k).sum()), mode="valid") for r in z])
+    p = 1.0 / (1.0 + np.exp(-3.0 * (z - 0.45)))
+    return np.ascontiguousarray(p.astype(np.float32).reshape(n_files, n_classes, n_frames).transpose(0, 2, 1))
+
+
+def bench_crnn_chain(args):
+    """BASELINE.json configs[2], the part behind the CRNN: sigmoid outputs (500 files, 862 frames, 5 classes) ->
+    gaussian smoothing + threshold + region decode (src/models/crnn/crnn.py:418-425, 454-459) -> gap merge at 0.3 / 0.6 /
+    1.0 s (src/utils/merge_events.py), with the event dictionaries formed on the host as the reference returns them.
+    One step = decode_probabilities + three merge_close_events_batch calls; the 8776-event result file of the
+    reference (tests/golden/crnn_kat.npz) is merged at the three gaps beside it."""
+    import numpy as np
+    import sed_amd
+    from sed_amd import decode as D
+    dev = torch.device("cuda", 0)
+    S, T, C, fps = 500, 862, 5, 44100 / 1024
+    labels = {0: "car_horn", 1: "cough", 2: "dog_bark", 3: "siren", 4: "gun_shot"}
+    files = [f"soundscape_{i:04d}.wav" for i in range(S)]
+    probs_host = crnn_probabilities(S, T, C, 418)
+    probs = torch.from_numpy(probs_host).to(dev)
+    gaps = (0.3, 0.6, 1.0)
+    table = torch.tensor([round(np.int64(k) * (1.0 / fps), 3) for k in range(T + 2)], dtype=torch.float64, device=dev)
+
+    def chain():
+        raw = D.decode_probabilities(probs, files, labels, fps)
+        return raw, [D.merge_close_events_batch(raw, g) for g in gaps]
+
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e3, out
+
+    chain_ms, (raw, merged) = timed(chain, args.steps, args.warmup)
+    decode_ms, _ = timed(lambda: D.decode_probabilities(probs, files, labels, fps), args.steps, 1)
+    merge_ms, _ = timed(lambda: D.merge_close_events_batch(raw, 0.6), args.steps, 1)
+    records_ms, rec = timed(lambda: [sed_amd.sharding.decode_and_exchange(probs, table, g, cap=64, smoothing="gauss") for g in gaps],
+                            args.steps, 1)
+    kern_ms, pcts, _ = time_kernel(lambda: D.threshold_runs(probs, 0.5, "gauss"), max(args.steps, 50), 5)
+    n_raw = sum(len(v) for v in raw.values())
+    n_merged = [sum(len(v) for v in m.values()) for m in merged]
+    # the reference's own result file through the merge at the three gaps
+    kat_path = os.path.join(ROOT, "tests", "golden", "crnn_kat.npz")
+    kat = None
+    if os.path.exists(kat_path):
+        pack = np.load(kat_path)
+        kfiles, klabels = [str(f) for f in pack["files"]], [str(l) for l in pack["labels"]]
+        kraw = {f: [] for f in kfiles}
+        for fi, li, on, off in zip(pack["raw_fi"], pack["raw_li"], pack["raw_on"], pack["raw_off"]):
+            kraw[kfiles[int(fi)]].append({"file": kfiles[int(fi)], "event_onset": float(on), "event_offset": float(off),
+                                          "event_label": klabels[int(li)]})
+        kat_ms, kout = timed(lambda: [D.merge_close_events_batch(kraw, g) for g in gaps], args.steps, args.warmup)
+        kat = {"events": sum(len(v) for v in kraw.values()), "files": len(kfiles), "merged_events": [sum(len(v) for v in m.values()) for m in kout],
+               "ms_three_gaps": kat_ms}
+    alg = S * T * C * 4
+    hours = S * 20.0 / 3600.0
+    res = {"metric": "log-mel audio-hours/sec", "value": hours / (chain_ms * 1e-3), "unit": "audio-hours/s", "n_gpus": 1,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": chain_ms, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f64 smoothing, f32 compare, int32 frames", "data": "synthetic",
+           "config": {"workload": "CRNN decode chain (BASELINE.json configs[2]): 500 files x 862 frames x 5 classes of 20 s audio -> gaussian "
+                                  "smoothing, threshold, region decode, gap merge at 0.3 / 0.6 / 1.0 s, host dictionaries included; value = "
+                                  "hours of audio whose frame probabilities are decoded per second",
+                      "raw_events": n_raw, "merged_events": n_merged, "decode_probabilities_ms": decode_ms,
+                      "merge_close_events_batch_ms_one_gap": merge_ms,
+                      "device_only_records_three_gaps_ms": records_ms,
+                      "device_only_note": "decode_and_exchange x 3: smoothing, threshold, runs, gap merge and (file, class, onset, offset) "
+                                          "frame records on the device, no host dictionaries",
+                      "reference_result_file": kat, "parallelism": "1 GPU"},
+           "roofline": {"bound": "hbm", "kernel": "threshold_runs_kernel<gauss25>", "achieved": alg / (kern_ms * 1e-3) / 1e9,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "algorithmic_bytes_per_launch": alg, "kernel_ms": kern_ms, "kernel_ms_p10_p50_p90": pcts,
+                        "note": "8.6 MB per launch: launch-bound, the chain's time is host formatting"}}
+    if not args.no_cpu_baseline:
+        from oracle.cpu_baseline import time_crnn_chain_cpu
+        v_ms, n, el, same = time_crnn_chain_cpu(probs_host, files, labels, fps, gaps, raw, merged, budget_s=10.0)
+        res["cpu_baseline"] = {"value": hours / (v_ms * 1e-3), "unit": "audio-hours/s", "cores": 1, "kind": "port",
+                               "ms_per_chain": v_ms, "same_events_as_device_chain": same,
+                               "sample": f"{n} passes over the same 500 files, {el:.1f} s of CPU work: scipy gaussian_filter1d + threshold + "
+                                         "the reference's per-file, per-class Python decode + its pure-Python merge at the three gaps",
+                               "host_cpus": os.cpu_count(), "cpu_model": cpu_model_name()}
+        if kat is not None:
+            from oracle import decode as od
+            t0 = time.perf_counter()
+            reps = 0
+            while time.perf_counter() - t0 < 2.0:
+                for g in gaps:
+                    {k: od.merge_close_events(v, g) for k, v in kraw.items()}
+                reps += 1
+            kat["cpu_ms_three_gaps"] = (time.perf_counter() - t0) / reps * 1e3
+    return res
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks (default: WORLD_SIZE under a launcher, else 1)")
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 1000; 20 for --workload crnn_chain)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default 100; 3 for --workload crnn_chain)")
+    ap.add_argument("--workload", choices=["htsat", "yamnet", "crnn_chain"], default="htsat",
+                    help="htsat: BASELINE.json configs[1], the headline line; yamnet: configs[0]; crnn_chain: configs[2]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
                     "rehearse the multi-rank control flow on a box with one GPU, together with --one-device)")
@@ -66,8 +271,23 @@ def main():
     ap.add_argument("--decode-stream", choices=["side", "same"], default="same",
                     help="side: the detector decode of a step runs on a second HIP stream beside the front-end kernel")
     args = ap.parse_args()
+    if args.gpus is None:                      # under a launcher the rank count is the launcher's
+        args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus < 1:
         raise SystemExit("--gpus must be at least 1")
+    if args.steps is None:
+        args.steps = 20 if args.workload == "crnn_chain" else 1000
+    if args.warmup is None:
+        args.warmup = 3 if args.workload == "crnn_chain" else 100
+    if args.workload != "htsat":
+        if args.gpus != 1 or int(os.environ.get("WORLD_SIZE", "1")) != 1:
+            raise SystemExit(f"--workload {args.workload} is a single-GPU line: run it with --gpus 1")
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a ROCm device: the hot path has no CPU fallback")
+        torch.cuda.set_device(0)
+        res = bench_yamnet(args) if args.workload == "yamnet" else bench_crnn_chain(args)
+        print(json.dumps(res), flush=True)
+        return
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # Not under torchrun: start the ranks as a fresh child process tree (nothing here has touched the GPU yet) and
@@ -192,6 +412,8 @@ def main():
         D.detect_onsets_offsets_batch(det2, 0.5, 0.48, True)
     host_fmt_ms = (time.perf_counter() - t1) / n_fmt * 1e3
 
+    h2d = measure_h2d(x) if rank == 0 else None
+
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tpath):
@@ -210,6 +432,7 @@ def main():
                    "parallelism": f"streams sharded over {world} GPU(s), all-gather of event record buffers",
                    "step_covers": "fused log-mel kernel + one decode kernel (median, threshold, runs, gap merge, event records) (+ all-gather for N > 1), "
                                   "all on the device; formatting events as host dictionaries is outside the step",
+                   "h2d_ms": h2d,
                    "decode_with_host_formatting_ms": host_fmt_ms,
                    "decode_with_host_formatting_note": "detect_onsets_offsets_batch on the same 256 streams: kernel + "
                                                        "device-to-host copy + Python formatting, per call"},
@@ -228,12 +451,7 @@ def main():
         torch.set_num_threads(1)
         v1, el1, n1 = time_htsat_cpu(sample[:2], budget_s=5.0)
         torch.set_num_threads(threads)
-        model = ""
-        try:
-            with open("/proc/cpuinfo") as f:
-                model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "")
-        except OSError:
-            pass
+        model = cpu_model_name()
         res["cpu_baseline"] = {"value": v, "unit": "audio-hours/s", "cores": threads, "kind": "port",
                                "sample": f"{n} passes over 8 of the 256 clips (10 s each), {el:.1f} s of CPU work, "
                                          "torchlibrosa formulation (fp32 conv-DFT + mel matmul + 10log10) on torch CPU",

@@ -163,7 +163,10 @@ int sed_db_normalize(float* x, int64_t groups, int64_t group_elems, int32_t subt
  * 64 KB array that the library holds on every GPU it runs on; it calls no allocating routine.  groups * pieces must
  * not exceed 16384, pieces = ceil(group_elems / 16384) (pieces of 32768, 65536, .. floats when that is more than 1024;
  * e.g. one group of 268 M floats, or 16 groups of 16 M), else SED_ERR_CAPACITY; groups <= 65535.  All calls on one GPU
- * share the array: calls that overlap in time on one GPU (different streams) race; calls of one stream do not. */
+ * share the array: calls that overlap in time on one GPU (different streams) race; calls of one stream do not.
+ * The first call on a device looks the array's address up (hipGetSymbolAddress, a synchronous runtime call that may
+ * initialise the code object): make one call per device BEFORE capturing a HIP graph that contains this entry point;
+ * every later call is stream operations only.  x must live on the current device, else SED_ERR_WRONG_DEVICE. */
 int sed_db_normalize_static(float* x, int64_t groups, int64_t group_elems, int32_t subtract_max, float top_db,
                             void* stream);
 

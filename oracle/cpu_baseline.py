@@ -1,4 +1,4 @@
-"""CPU baseline for bench.py: the reference's own formulation of the HTS-AT front-end on host cores.
+"""CPU baselines for bench.py: the reference's own formulations of the hot path on host cores.
 TEST / MEASUREMENT INFRASTRUCTURE ONLY (never imported by the product package).
 
 torchlibrosa computes the STFT as two Conv1d with fp32 windowed-DFT weights over the reflect-padded waveform,
@@ -49,3 +49,59 @@ def time_htsat_cpu(clips: torch.Tensor, budget_s: float = 15.0):
             break
     hours = n * clips.shape[0] * clips.shape[1] / 32000.0 / 3600.0
     return hours / el, el, n
+
+
+class YamnetCpuFrontend:
+    """YAMNet's feature graph as TensorFlow forms it (tensorflow/models research/audioset/yamnet/features.py, called
+    inside the hub model at src/models/yamnet_train.py:46-47): pad_waveform, tf.signal.stft(400, 160, fft_length 512) =
+    frame + periodic Hann + rFFT, magnitude, matmul with linear_to_mel_weight_matrix, log(mel + 0.001)."""
+
+    def __init__(self):
+        self.window = torch.from_numpy(of.hann_periodic(400).astype(np.float32))
+        self.melW = torch.from_numpy(of.tf_linear_to_mel_weight_matrix().astype(np.float32))
+
+    @torch.no_grad()
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        pad = of.yamnet_padded_length(x.shape[-1]) - x.shape[-1]
+        x = F.pad(x, (0, pad))
+        frames = x.unfold(-1, 400, 160) * self.window
+        mag = torch.fft.rfft(frames, n=512).abs()
+        return torch.log(torch.matmul(mag, self.melW) + 0.001)
+
+
+def time_cpu_frontend(fe, clips: torch.Tensor, sr: int, budget_s: float = 10.0):
+    """Audio-hours/s of a CPU front-end on `clips` (B, L) fp32; repeats until ~budget_s of work."""
+    fe(clips[:1])
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        fe(clips)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 2000:
+            break
+    return n * clips.shape[0] * clips.shape[1] / float(sr) / 3600.0 / el, el, n
+
+
+def time_crnn_chain_cpu(probs, files, labels, fps, gaps, want_raw=None, want_merged=None, budget_s: float = 10.0):
+    """The reference's decode chain behind the CRNN on the host, as it runs it: scipy's gaussian_filter1d and the
+    threshold (src/models/crnn/crnn.py:418-425), the per-file, per-class Python region decode
+    (src/models/crnn/utils.py:91-134) and the pure-Python gap merge per file (src/utils/merge_events.py:4-60) at every
+    gap.  Returns (ms per chain, passes, seconds, whether the events equal want_raw / want_merged)."""
+    from scipy.ndimage import gaussian_filter1d
+    from . import decode as od
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        sm = gaussian_filter1d(probs, sigma=3, axis=1, mode="nearest")
+        act = (sm > 0.5).astype(int)
+        raw = od.decode_predictions(act, files, labels, fps)
+        merged = [{k: od.merge_close_events(v, g) for k, v in raw.items()} for g in gaps]
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s:
+            break
+    same = None
+    if want_raw is not None:
+        same = bool(raw == want_raw and all(a == b for a, b in zip(merged, want_merged)))
+    return el / n * 1e3, n, el, same

@@ -1228,7 +1228,14 @@ extern "C" int sed_plan_set_affine(sed_plan* pl, const float* scale, const float
     if (!rc) rc = upload(&pl->d_shift, pl->shift_host);
     if (rc) return rc;
   }
-  return upload_tables(pl);
+  // Only the 256 affine floats of the LDS image change: the mel schedule and the other tables stay as they are.
+  if (!pl->d_image || pl->image_host.size() < (size_t)pl->im.off_aff + 256) return upload_tables(pl);
+  float* aff = pl->image_host.data() + pl->im.off_aff;
+  for (int m = 0; m < 128; ++m) {
+    aff[m] = (pl->affine && m < M) ? pl->scale_host[m] : 0.0f;
+    aff[128 + m] = (pl->affine && m < M) ? pl->shift_host[m] : 0.0f;
+  }
+  return hip_status(hipMemcpy(pl->d_image + pl->im.off_aff, aff, 256 * sizeof(float), hipMemcpyHostToDevice));
 }
 
 template <class G, bool MAG, bool SPEC_OUT, bool PRE, class Mel>
@@ -1559,6 +1566,18 @@ extern "C" int sed_db_normalize_static(float* x, int64_t groups, int64_t group_e
   int dev = -1;
   SED_HIP_TRY(hipGetDevice(&dev));
   if (dev < 0 || dev >= 16) return SED_ERR_BAD_ARG;
+  hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing((hipStream_t)stream, &capturing) != hipSuccess) { (void)hipGetLastError(); capturing = hipStreamCaptureStatusNone; }
+  if (capturing == hipStreamCaptureStatusNone) {
+    // the scratch array is the current device's: data that lives on another GPU is refused (a query, no allocation;
+    // left out under stream capture, where the call is stream operations only)
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, x) == hipSuccess) {
+      if (attr.type == hipMemoryTypeDevice && attr.device != dev) return SED_ERR_WRONG_DEVICE;
+    } else {
+      (void)hipGetLastError();  // an unregistered pointer: let the launch report it
+    }
+  }
   float* partial = nullptr;
   {
     std::lock_guard<std::mutex> lock(mu);

@@ -222,21 +222,37 @@ def detect_onsets_offsets_batch(preds, threshold=0.5, hop_time=0.48, med_filter=
 # ---- D2 + D3 ---------------------------------------------------------------------------------------------
 
 
-def _format_events(results, filenames, class_labels, frames_per_sec, n_files, get_pairs):
+def _format_events(results, filenames, class_labels, frames_per_sec, starts, ends, counts):
+    """Host formatting of crnn/utils.py:99-134 for all files in a few numpy calls: starts / ends (N, C, cap) frame
+    indices and counts (N, C) -> {file: [event dicts]}, class-major in the order of class_labels, onset-ascending."""
     time_resolution = 1.0 / frames_per_sec
+    n_files = min(starts.shape[0], len(filenames))
+    names = []
     for i in range(n_files):
-        if i >= len(filenames):
-            break
         filename = filenames[i]
         if isinstance(filename, np.ndarray):
             filename = filename.item()
-        filename = str(filename)
-        results[filename] = []
-        for class_idx, label in class_labels.items():
-            for s, e in get_pairs(i, class_idx):
-                # np.int64 * float -> np.float64, whose round() is numpy's (crnn/utils.py:122-129 does the same)
-                results[filename].append({"file": filename, "event_onset": round(np.int64(s) * time_resolution, 3),
-                                          "event_offset": round(np.int64(e) * time_resolution, 3), "event_label": label})
+        names.append(str(filename))
+    order = list(class_labels.keys())
+    labels = list(class_labels.values())
+    if n_files == 0 or not order:
+        for name in names:
+            results[name] = []
+        return results
+    cnt = counts[:n_files][:, order]                                             # (n, K) in dict order
+    live = np.arange(starts.shape[2])[None, None, :] < cnt[:, :, None]
+    # np.int64 * float -> np.float64, rounded by numpy (rint(x * 1000) / 1000), as round() of the reference's np.float64
+    # products does (crnn/utils.py:122-129)
+    on = np.round(starts[:n_files][:, order][live].astype(np.int64) * time_resolution, 3)
+    off = np.round(ends[:n_files][:, order][live].astype(np.int64) * time_resolution, 3)
+    lab = np.broadcast_to(np.arange(len(order))[None, :, None], live.shape)[live]
+    per_file = cnt.sum(axis=1)
+    bounds = np.concatenate([[0], np.cumsum(per_file)])
+    file_of = np.repeat(np.arange(n_files), per_file)
+    events = [{"file": names[f], "event_onset": a, "event_offset": b, "event_label": labels[c]}
+              for f, a, b, c in zip(file_of.tolist(), on, off, lab.tolist())]
+    for i, name in enumerate(names):
+        results[name] = events[bounds[i]:bounds[i + 1]]
     return results
 
 
@@ -244,12 +260,7 @@ def decode_predictions(preds, filenames, class_labels, frames_per_sec):
     """Binary activity (N, T, C) -> {file: [{'file','event_onset','event_offset','event_label'}]}."""
     a = _to_dev(preds, torch.int32)
     starts, ends, ns, ne = (t.cpu().numpy() for t in activity_edges(a))
-
-    def pairs(i, c):
-        n = min(ns[i, c], ne[i, c])
-        return zip(starts[i, c, :n], ends[i, c, :n])
-
-    return _format_events({}, filenames, class_labels, frames_per_sec, a.shape[0], pairs)
+    return _format_events({}, filenames, class_labels, frames_per_sec, starts, ends, np.minimum(ns, ne))
 
 
 def decode_probabilities(probs, filenames, class_labels, frames_per_sec, posterior_thresh=0.5, smoothing="gauss"):
@@ -257,55 +268,69 @@ def decode_probabilities(probs, filenames, class_labels, frames_per_sec, posteri
     p = _to_dev(probs, torch.float32)
     runs, counts = threshold_runs(p, posterior_thresh, smoothing)
     runs, counts = runs.cpu().numpy(), counts.cpu().numpy()
-
-    def pairs(i, c):
-        return runs[i, c, :counts[i, c]]
-
-    return _format_events({}, filenames, class_labels, frames_per_sec, p.shape[0], pairs)
+    return _format_events({}, filenames, class_labels, frames_per_sec, runs[..., 0], runs[..., 1], counts)
 
 
 # ---- D4 --------------------------------------------------------------------------------------------------
 
 
 def merge_close_events_batch(events_by_file: Dict[str, List[Dict[str, Any]]], threshold: float = 0.5):
-    """merge_close_events for every file of a results dict with ONE kernel launch."""
+    """merge_close_events for every file of a results dict with ONE kernel launch.  The grouping of the reference
+    (stable sort by onset, groups by label in order of first appearance, final stable sort by onset:
+    src/utils/merge_events.py:19-33, 57-58) is done for all files at once with stable numpy sorts; the only per-event
+    Python work is reading the input dicts and copying the dicts of the merged events."""
     keys = list(events_by_file.keys())
-    heads: List[List[Dict[str, Any]]] = []   # per group: its events in onset order
-    owner: List[int] = []                    # per group: index of the file
-    for fi, k in enumerate(keys):
-        events = events_by_file[k]
-        if not events:
-            continue
-        sorted_events = sorted(events, key=lambda x: x["event_onset"])
-        by_label: Dict[Any, List[Dict[str, Any]]] = {}
-        for ev in sorted_events:
-            by_label.setdefault(ev["event_label"], []).append(ev)
-        for label_events in by_label.values():
-            heads.append(label_events)
-            owner.append(fi)
     out = {k: [] for k in keys}
-    if heads:
-        sizes = np.asarray([len(g) for g in heads], dtype=np.int64)
-        group_start = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
-        on = np.asarray([ev["event_onset"] for g in heads for ev in g], dtype=np.float64)
-        off = np.asarray([ev["event_offset"] for g in heads for ev in g], dtype=np.float64)
-        dev = _device()
-        m_on, m_off, m_cnt = merge_event_groups(torch.from_numpy(on).to(dev), torch.from_numpy(off).to(dev),
-                                                torch.from_numpy(group_start).to(dev), threshold)
-        m_on, m_off, m_cnt = m_on.cpu().numpy(), m_off.cpu().numpy(), m_cnt.cpu().numpy()
-        for gi, g in enumerate(heads):
-            base = int(group_start[gi])
-            # a merged event is a copy of the first event folded into it; find that event by walking the group
-            j = 0
-            for r in range(int(m_cnt[gi])):
-                while g[j]["event_onset"] != m_on[base + r]:
-                    j += 1
-                ev = g[j].copy()
-                ev["event_offset"] = float(m_off[base + r])
-                out[keys[owner[gi]]].append(ev)
-                j += 1
-    for k in keys:
-        out[k].sort(key=lambda x: x["event_onset"])
+    lens = [len(events_by_file[k]) for k in keys]
+    flat = [ev for k in keys for ev in events_by_file[k]]
+    n = len(flat)
+    if n == 0:
+        return out
+    on = np.fromiter((ev["event_onset"] for ev in flat), np.float64, n)
+    off = np.fromiter((ev["event_offset"] for ev in flat), np.float64, n)
+    ids: Dict[Any, int] = {}
+    lab = np.fromiter((ids.setdefault(ev["event_label"], len(ids)) for ev in flat), np.int64, n)
+    file_idx = np.repeat(np.arange(len(keys)), lens)
+    # events of a file in onset order (stable), then the (file, label) groups in the order their first event appears
+    by_onset = np.lexsort((on, file_idx))
+    gkey = file_idx[by_onset] * len(ids) + lab[by_onset]
+    _, first_pos, inv = np.unique(gkey, return_index=True, return_inverse=True)
+    first_of_event = first_pos[inv]
+    grouped = np.lexsort((np.arange(n), first_of_event))          # positions in by_onset, group after group
+    src = by_onset[grouped]                                       # index into `flat` of the event at each grouped slot
+    g_first = first_of_event[grouped]
+    starts = np.flatnonzero(np.concatenate([[True], g_first[1:] != g_first[:-1]]))
+    group_start = np.concatenate([starts, [n]]).astype(np.int32)
+    sizes = np.diff(group_start)
+    n_groups = len(sizes)
+    g_on, g_off = on[src], off[src]
+    dev = _device()
+    m_on, m_off, m_cnt = merge_event_groups(torch.from_numpy(g_on).to(dev), torch.from_numpy(g_off).to(dev),
+                                            torch.from_numpy(group_start).to(dev), threshold)
+    m_on, m_off, m_cnt = m_on.cpu().numpy(), m_off.cpu().numpy(), m_cnt.cpu().numpy().astype(np.int64)
+    total = int(m_cnt.sum())
+    gid = np.repeat(np.arange(n_groups), m_cnt)                   # group of every merged event
+    slot = np.repeat(group_start[:-1].astype(np.int64), m_cnt) + (np.arange(total) - np.repeat(np.cumsum(m_cnt) - m_cnt, m_cnt))
+    h_on, h_off = m_on[slot], m_off[slot]
+    # A merged event is a copy of the first event folded into it: the first event of its group, at or behind the previous
+    # merged event's, whose onset is the merged onset.  Onsets ascend inside a group, so with the onsets replaced by their
+    # ranks among all values, (group, rank) ascends over the grouped array and one binary search finds every such event.
+    uniq = np.unique(g_on)
+    key_ev = np.repeat(np.arange(n_groups), sizes) * (len(uniq) + 1) + np.searchsorted(uniq, g_on)
+    key_h = gid * (len(uniq) + 1) + np.searchsorted(uniq, h_on)
+    head = np.searchsorted(key_ev, key_h, side="left")
+    if total > 1:                                                 # merged events of one group that share an onset: one after another
+        same = np.concatenate([[False], key_h[1:] == key_h[:-1]])
+        run_start = np.maximum.accumulate(np.where(same, 0, np.arange(total)))
+        head = head + (np.arange(total) - run_start)
+    # merged events of a file: its groups one after the other, then a stable sort by onset (merge_events.py:57-58)
+    file_of = file_idx[by_onset][g_first[group_start[:-1]]][gid]
+    final = np.lexsort((np.arange(total), h_on, file_of))
+    lists = [out[k] for k in keys]
+    for j, o, f in zip(src[head[final]].tolist(), h_off[final].tolist(), file_of[final].tolist()):
+        ev = flat[j].copy()
+        ev["event_offset"] = o
+        lists[f].append(ev)
     return out
 
 

@@ -247,21 +247,37 @@ class _STFTTables(nn.Module):
     quarter of the entries differ by one fp32 ulp from the exactly reduced angle cos/sin(2 pi (n k mod N) / N).  The kernels
     do not read these tensors."""
 
+    _cache: dict = {}   # (n_fft, win_length) -> (real, imag) fp32 arrays (F, 1, n_fft), shared by construction and load checks
+
+    @classmethod
+    def weights(cls, n_fft: int, win_length: int):
+        key = (int(n_fft), int(win_length))
+        hit = cls._cache.get(key)
+        if hit is None:
+            # the fp64 window of scipy.signal.get_window('hann', win_length, fftbins=True) (general_cosine: 0.5 + 0.5 cos(fac),
+            # fac = linspace(-pi, pi, win_length + 1) without its last point), centred in n_fft samples like librosa.util.pad_center
+            fac = np.linspace(-np.pi, np.pi, win_length + 1)[:-1]
+            win = np.zeros(win_length)
+            for k, a in enumerate((0.5, 0.5)):
+                win += a * np.cos(k * fac)
+            lpad = (n_fft - win_length) // 2
+            window_full = np.pad(win, (lpad, n_fft - win_length - lpad))
+            # columns 0 .. n_fft/2 of torchlibrosa's n_fft x n_fft matrix, the only ones it keeps (same elementwise expressions)
+            (x, y) = np.meshgrid(np.arange(n_fft // 2 + 1), np.arange(n_fft))
+            omega = np.exp(-2 * np.pi * 1j / n_fft)
+            W = np.power(omega, x * y) * window_full[:, None]
+            hit = (np.ascontiguousarray(np.real(W).T.astype(np.float32)[:, None, :]),
+                   np.ascontiguousarray(np.imag(W).T.astype(np.float32)[:, None, :]))
+            for a in hit:
+                a.setflags(write=False)
+            cls._cache[key] = hit
+        return hit
+
     def __init__(self, n_fft: int, win_length: int):
         super().__init__()
-        # the fp64 window of scipy.signal.get_window('hann', win_length, fftbins=True) (general_cosine: 0.5 + 0.5 cos(fac),
-        # fac = linspace(-pi, pi, win_length + 1) without its last point), centred in n_fft samples like librosa.util.pad_center
-        fac = np.linspace(-np.pi, np.pi, win_length + 1)[:-1]
-        win = np.zeros(win_length)
-        for k, a in enumerate((0.5, 0.5)):
-            win += a * np.cos(k * fac)
-        lpad = (n_fft - win_length) // 2
-        window_full = np.pad(win, (lpad, n_fft - win_length - lpad))
-        (x, y) = np.meshgrid(np.arange(n_fft), np.arange(n_fft))
-        omega = np.exp(-2 * np.pi * 1j / n_fft)
-        W = np.power(omega, x * y)[:, 0:n_fft // 2 + 1] * window_full[:, None]
-        self.conv_real = _ConvWeight(torch.from_numpy(np.real(W).T.astype(np.float32))[:, None, :].contiguous())
-        self.conv_imag = _ConvWeight(torch.from_numpy(np.imag(W).T.astype(np.float32))[:, None, :].contiguous())
+        real, imag = self.weights(n_fft, win_length)
+        self.conv_real = _ConvWeight(torch.from_numpy(real.copy()))
+        self.conv_imag = _ConvWeight(torch.from_numpy(imag.copy()))
 
 
 class Spectrogram(_PlanHolder):
@@ -303,10 +319,10 @@ class Spectrogram(_PlanHolder):
 
 
 def _check_stft_tables(module, incompatible_keys):
-    ref = _STFTTables(module.n_fft, module.win_length)
+    ref = dict(zip(("conv_real", "conv_imag"), _STFTTables.weights(module.n_fft, module.win_length)))
     for name in ("conv_real", "conv_imag"):
         got = getattr(module.stft, name).weight.detach().cpu()
-        if not torch.allclose(got, getattr(ref, name).weight, atol=1e-5, rtol=0):
+        if got.shape != ref[name].shape or not torch.allclose(got, torch.from_numpy(ref[name].copy()), atol=1e-5, rtol=0):
             raise RuntimeError(f"loaded stft.{name}.weight is not the Hann-windowed DFT matrix this module computes")
 
 

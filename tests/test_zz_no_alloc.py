@@ -52,3 +52,33 @@ def test_static_db_normalize_equals_the_allocating_entry_point():
     rc = lib.sed_db_normalize_static(C.c_void_p(big.data_ptr()), 20000, 16385, 1, C.c_float(80.0), C.c_void_p(stream))
     assert rc == -3
     assert "capacity" in L.lib.sed_status_string(rc).decode()
+
+
+def test_static_db_normalize_under_graph_capture():
+    """After one eager call on the device (which looks the scratch address up), the entry point is stream operations
+    only: captured in a HIP graph and replayed on new data it gives the eager result."""
+    import sed_amd._lib as L
+    lib = L.lib
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(9)
+    buf = -60.0 * torch.rand((2, 300001), generator=g, device=dev)
+    warm = buf.clone()
+    assert lib.sed_db_normalize_static(C.c_void_p(warm.data_ptr()), 2, 300001, 1, C.c_float(80.0),
+                                       C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)) == 0
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        rc = lib.sed_db_normalize_static(C.c_void_p(buf.data_ptr()), 2, 300001, 1, C.c_float(80.0),
+                                         C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    assert rc == 0
+    for seed in (1, 2):
+        fresh = -60.0 * torch.rand((2, 300001), generator=torch.Generator(device=dev).manual_seed(seed), device=dev)
+        fresh[seed - 1, 12345 * seed] = 1.25
+        buf.copy_(fresh)
+        graph.replay()
+        torch.cuda.synchronize()
+        want = fresh.clone()
+        assert lib.sed_db_normalize(C.c_void_p(want.data_ptr()), 2, 300001, 1, C.c_float(80.0),
+                                    C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(buf, want)
