@@ -170,7 +170,7 @@ def bench_crnn_chain(args):
     """BASELINE.json configs[2], the part behind the CRNN: sigmoid outputs (500 files, 862 frames, 5 classes) ->
     gaussian smoothing + threshold + region decode (src/models/crnn/crnn.py:418-425, 454-459) -> gap merge at 0.3 / 0.6 /
     1.0 s (src/utils/merge_events.py), with the event dictionaries formed on the host as the reference returns them.
-    One step = decode_probabilities + three merge_close_events_batch calls; the 8776-event result file of the
+    One step = decode_probabilities + merge_close_events_batch at the three gaps (events read and grouped once); the 8776-event result file of the
     reference (tests/golden/crnn_kat.npz) is merged at the three gaps beside it."""
     import numpy as np
     import sed_amd
@@ -186,7 +186,7 @@ def bench_crnn_chain(args):
 
     def chain():
         raw = D.decode_probabilities(probs, files, labels, fps)
-        return raw, [D.merge_close_events_batch(raw, g) for g in gaps]
+        return raw, D.merge_close_events_batch(raw, list(gaps))
 
     def timed(fn, steps, warmup):
         for _ in range(warmup):
@@ -216,7 +216,7 @@ def bench_crnn_chain(args):
         for fi, li, on, off in zip(pack["raw_fi"], pack["raw_li"], pack["raw_on"], pack["raw_off"]):
             kraw[kfiles[int(fi)]].append({"file": kfiles[int(fi)], "event_onset": float(on), "event_offset": float(off),
                                           "event_label": klabels[int(li)]})
-        kat_ms, kout = timed(lambda: [D.merge_close_events_batch(kraw, g) for g in gaps], args.steps, args.warmup)
+        kat_ms, kout = timed(lambda: D.merge_close_events_batch(kraw, list(gaps)), args.steps, args.warmup)
         kat = {"events": sum(len(v) for v in kraw.values()), "files": len(kfiles), "merged_events": [sum(len(v) for v in m.values()) for m in kout],
                "ms_three_gaps": kat_ms}
     alg = S * T * C * 4

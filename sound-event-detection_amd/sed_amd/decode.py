@@ -17,7 +17,9 @@ bit-identical given identical frame probabilities.  There is no CPU path.
 """
 from __future__ import annotations
 
+import itertools
 import json
+import operator
 import os
 from typing import Any, Dict, List, Sequence
 
@@ -28,6 +30,7 @@ from . import _lib as L
 
 CLASSES = ["cough", "dog_bark", "gun_shot", "siren", "car_horn"]           # src/config.py:4
 NON_EVENT_LABEL = "non_event"                                               # src/models/htsat/constants.py:8
+_EVENT_FIELDS = operator.itemgetter("event_onset", "event_offset", "event_label")
 _SMOOTH = {None: L.SMOOTH_NONE, "none": L.SMOOTH_NONE, "median3": L.SMOOTH_MEDIAN3, "gauss": L.SMOOTH_GAUSS25}
 
 
@@ -267,29 +270,66 @@ def decode_probabilities(probs, filenames, class_labels, frames_per_sec, posteri
     """Sigmoid outputs (N, T, C) -> events: gaussian smoothing (sigma 3, 'nearest'), strict threshold, run decode."""
     p = _to_dev(probs, torch.float32)
     runs, counts = threshold_runs(p, posterior_thresh, smoothing)
+    if p.shape[0] and list(class_labels.keys()) == list(range(p.shape[2])):
+        # The usual label dict (every class, in index order) is the record packer's own order: the runs are compacted on
+        # the device into (file, class, onset, offset) records, sized for the busiest file, and only those come to the host.
+        from . import sharding
+        most = int(counts.sum(dim=1).max().item())
+        rec = sharding.pack_events(runs, counts, cap=max(most, 1)).cpu().numpy()
+        return _format_records({}, rec, filenames, list(class_labels.values()), frames_per_sec)
     runs, counts = runs.cpu().numpy(), counts.cpu().numpy()
     return _format_events({}, filenames, class_labels, frames_per_sec, runs[..., 0], runs[..., 1], counts)
+
+
+def _format_records(results, rec, filenames, labels, frames_per_sec):
+    """_format_events for the packed records of sharding.pack_events: rec (N, cap + 1, 4), row 0 = (kept, dropped, 0, 0),
+    rows 1.. = (file, class, onset frame, offset frame), class-major and onset-ascending."""
+    time_resolution = 1.0 / frames_per_sec
+    n_files = min(rec.shape[0], len(filenames))
+    names = []
+    for i in range(n_files):
+        filename = filenames[i]
+        if isinstance(filename, np.ndarray):
+            filename = filename.item()
+        names.append(str(filename))
+    kept = rec[:n_files, 0, 0].astype(np.int64)
+    live = np.arange(rec.shape[1] - 1)[None, :] < kept[:, None]
+    body = rec[:n_files, 1:]
+    on = np.round(body[..., 2][live].astype(np.int64) * time_resolution, 3)   # numpy's rounding, see _format_events
+    off = np.round(body[..., 3][live].astype(np.int64) * time_resolution, 3)
+    bounds = np.concatenate([[0], np.cumsum(kept)]).tolist()
+    events = [{"file": names[f], "event_onset": a, "event_offset": b, "event_label": labels[c]}
+              for f, a, b, c in zip(np.repeat(np.arange(n_files), kept).tolist(), on, off, body[..., 1][live].tolist())]
+    for i, name in enumerate(names):
+        results[name] = events[bounds[i]:bounds[i + 1]]
+    return results
 
 
 # ---- D4 --------------------------------------------------------------------------------------------------
 
 
-def merge_close_events_batch(events_by_file: Dict[str, List[Dict[str, Any]]], threshold: float = 0.5):
+def merge_close_events_batch(events_by_file: Dict[str, List[Dict[str, Any]]], threshold=0.5):
     """merge_close_events for every file of a results dict with ONE kernel launch.  The grouping of the reference
     (stable sort by onset, groups by label in order of first appearance, final stable sort by onset:
     src/utils/merge_events.py:19-33, 57-58) is done for all files at once with stable numpy sorts; the only per-event
-    Python work is reading the input dicts and copying the dicts of the merged events."""
+    Python work is reading the input dicts and copying the dicts of the merged events.
+
+    `threshold` may be a sequence of gaps (the reference's result files use 0.3, 0.6 and 1.0 s): the events are read
+    and grouped once, every gap is one launch, and a list of result dicts comes back."""
+    many = isinstance(threshold, (list, tuple))
+    gaps = list(threshold) if many else [threshold]
     keys = list(events_by_file.keys())
-    out = {k: [] for k in keys}
     lens = [len(events_by_file[k]) for k in keys]
-    flat = [ev for k in keys for ev in events_by_file[k]]
+    flat = list(itertools.chain.from_iterable(events_by_file.values()))
     n = len(flat)
     if n == 0:
-        return out
-    on = np.fromiter((ev["event_onset"] for ev in flat), np.float64, n)
-    off = np.fromiter((ev["event_offset"] for ev in flat), np.float64, n)
-    ids: Dict[Any, int] = {}
-    lab = np.fromiter((ids.setdefault(ev["event_label"], len(ids)) for ev in flat), np.int64, n)
+        outs = [{k: [] for k in keys} for _ in gaps]
+        return outs if many else outs[0]
+    cols = list(zip(*map(_EVENT_FIELDS, flat)))
+    on = np.array(cols[0], dtype=np.float64)
+    off = np.array(cols[1], dtype=np.float64)
+    ids = {lbl: i for i, lbl in enumerate(dict.fromkeys(cols[2]))}
+    lab = np.array(list(map(ids.__getitem__, cols[2])), dtype=np.int64)
     file_idx = np.repeat(np.arange(len(keys)), lens)
     # events of a file in onset order (stable), then the (file, label) groups in the order their first event appears
     by_onset = np.lexsort((on, file_idx))
@@ -304,34 +344,36 @@ def merge_close_events_batch(events_by_file: Dict[str, List[Dict[str, Any]]], th
     sizes = np.diff(group_start)
     n_groups = len(sizes)
     g_on, g_off = on[src], off[src]
-    dev = _device()
-    m_on, m_off, m_cnt = merge_event_groups(torch.from_numpy(g_on).to(dev), torch.from_numpy(g_off).to(dev),
-                                            torch.from_numpy(group_start).to(dev), threshold)
-    m_on, m_off, m_cnt = m_on.cpu().numpy(), m_off.cpu().numpy(), m_cnt.cpu().numpy().astype(np.int64)
-    total = int(m_cnt.sum())
-    gid = np.repeat(np.arange(n_groups), m_cnt)                   # group of every merged event
-    slot = np.repeat(group_start[:-1].astype(np.int64), m_cnt) + (np.arange(total) - np.repeat(np.cumsum(m_cnt) - m_cnt, m_cnt))
-    h_on, h_off = m_on[slot], m_off[slot]
-    # A merged event is a copy of the first event folded into it: the first event of its group, at or behind the previous
-    # merged event's, whose onset is the merged onset.  Onsets ascend inside a group, so with the onsets replaced by their
-    # ranks among all values, (group, rank) ascends over the grouped array and one binary search finds every such event.
+    file_of_group = file_idx[by_onset][g_first[group_start[:-1]]]
+    # Onsets ascend inside a group, so with the onsets replaced by their ranks among all values, (group, rank) ascends
+    # over the grouped array and one binary search finds the event that opens each merged event (below).
     uniq = np.unique(g_on)
     key_ev = np.repeat(np.arange(n_groups), sizes) * (len(uniq) + 1) + np.searchsorted(uniq, g_on)
-    key_h = gid * (len(uniq) + 1) + np.searchsorted(uniq, h_on)
-    head = np.searchsorted(key_ev, key_h, side="left")
-    if total > 1:                                                 # merged events of one group that share an onset: one after another
-        same = np.concatenate([[False], key_h[1:] == key_h[:-1]])
-        run_start = np.maximum.accumulate(np.where(same, 0, np.arange(total)))
-        head = head + (np.arange(total) - run_start)
-    # merged events of a file: its groups one after the other, then a stable sort by onset (merge_events.py:57-58)
-    file_of = file_idx[by_onset][g_first[group_start[:-1]]][gid]
-    final = np.lexsort((np.arange(total), h_on, file_of))
-    lists = [out[k] for k in keys]
-    for j, o, f in zip(src[head[final]].tolist(), h_off[final].tolist(), file_of[final].tolist()):
-        ev = flat[j].copy()
-        ev["event_offset"] = o
-        lists[f].append(ev)
-    return out
+    dev = _device()
+    d_on, d_off, d_start = torch.from_numpy(g_on).to(dev), torch.from_numpy(g_off).to(dev), torch.from_numpy(group_start).to(dev)
+    launched = [merge_event_groups(d_on, d_off, d_start, gap) for gap in gaps]
+    outs = []
+    for m_on, m_off, m_cnt in launched:
+        m_on, m_off, m_cnt = m_on.cpu().numpy(), m_off.cpu().numpy(), m_cnt.cpu().numpy().astype(np.int64)
+        total = int(m_cnt.sum())
+        gid = np.repeat(np.arange(n_groups), m_cnt)               # group of every merged event
+        slot = np.repeat(group_start[:-1].astype(np.int64), m_cnt) + (np.arange(total) - np.repeat(np.cumsum(m_cnt) - m_cnt, m_cnt))
+        h_on, h_off = m_on[slot], m_off[slot]
+        # A merged event is a copy of the first event folded into it: the first event of its group, at or behind the
+        # previous merged event's, whose onset is the merged onset.
+        key_h = gid * (len(uniq) + 1) + np.searchsorted(uniq, h_on)
+        head = np.searchsorted(key_ev, key_h, side="left")
+        if total > 1:                                             # merged events of one group that share an onset: one after another
+            same = np.concatenate([[False], key_h[1:] == key_h[:-1]])
+            run_start = np.maximum.accumulate(np.where(same, 0, np.arange(total)))
+            head = head + (np.arange(total) - run_start)
+        # merged events of a file: its groups one after the other, then a stable sort by onset (merge_events.py:57-58)
+        file_of = file_of_group[gid]
+        final = np.lexsort((np.arange(total), h_on, file_of))
+        merged = [{**flat[j], "event_offset": o} for j, o in zip(src[head[final]].tolist(), h_off[final].tolist())]
+        bounds = np.searchsorted(file_of[final], np.arange(len(keys) + 1), side="left").tolist()
+        outs.append({k: merged[bounds[i]:bounds[i + 1]] for i, k in enumerate(keys)})
+    return outs if many else outs[0]
 
 
 def merge_close_events(events: List[Dict[str, Any]], threshold: float = 0.5) -> List[Dict[str, Any]]:

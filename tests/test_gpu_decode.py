@@ -57,6 +57,7 @@ def test_merge_random_overlapping_and_long_groups():
         got = sed_amd.merge_close_events_batch(data, thr)
         want = {k: od.merge_close_events(v, thr) for k, v in data.items()}
         assert got == want, thr
+        assert all("extra" in e for v in got.values() for e in v)        # a merged event is a copy of its first event
 
 
 def test_decode_predictions_roundtrip(kat, golden_dir):
@@ -94,6 +95,19 @@ def test_full_crnn_chain_on_synthetic_probabilities(kat):
     assert n_ev > 2000
     for thr in (0.3, 0.6, 1.0):
         assert sed_amd.merge_close_events_batch(got, thr) == {k: od.merge_close_events(v, thr) for k, v in want.items()}
+    # several gaps in one call (events read and grouped once)
+    three = sed_amd.merge_close_events_batch(got, [0.3, 0.6, 1.0])
+    assert three == [{k: od.merge_close_events(v, thr) for k, v in want.items()} for thr in (0.3, 0.6, 1.0)]
+    assert sed_amd.merge_close_events_batch({}, [0.3, 0.6]) == [{}, {}]
+    # label dicts that are not "every class in index order" take the general formatting path: a subset in another order,
+    # fewer names than predictions, numpy names
+    sub = {3: "siren", 0: "car_horn"}
+    assert sed_amd.decode_probabilities(probs[:40], files[:40], sub, fps, 0.5) == \
+        od.decode_predictions(od.smooth_and_threshold(probs[:40], 0.5), files[:40], sub, fps)
+    assert sed_amd.decode_probabilities(probs[:9], np.asarray(files[:7]), idx_to_label, fps, 0.5) == \
+        od.decode_predictions(od.smooth_and_threshold(probs[:9], 0.5), np.asarray(files[:7]), idx_to_label, fps)
+    silent = np.zeros((3, 50, 5), np.float32)
+    assert sed_amd.decode_probabilities(silent, files[:3], idx_to_label, fps, 0.5) == {f: [] for f in files[:3]}
 
 
 def test_decode_predictions_rounding_at_other_frame_rates(golden_dir):
