@@ -134,7 +134,7 @@ static double check_mel_schedule(int sr, int n_fft, int M, double fmin, double f
         for (int block = 0; block < 16; ++block)
           for (int i = 0; i < 4; ++i)
             for (int j = 0; j < 4; ++j) {
-              const float a = sc.a[(((size_t)set * (U + 1) + u) * 64 + 4 * block + i) * 4 + e];
+              const float a = sc.a[(((size_t)set * U + u) * 64 + 4 * block + i) * 4 + e];
               const float b = pw[j * pitch + sc.base[set * 16 + block] + 4 * u + e];
               part[((size_t)sc.slot[set * 16 + block] * 4 + i) * 4 + j] += (double)a * b;
             }

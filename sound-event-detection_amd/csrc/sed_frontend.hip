@@ -52,6 +52,7 @@ constexpr int kMaxSpanBlocks = 32;  // 1 KB blocks of a staged span: (FPW - 1) *
 // for the fused kernel [mel weights | per-lane B-operand offsets | per-lane gather words | affine | 4 zeros].
 struct ImageLayout {
   int32_t off_tw1, off_tw2, off_mela, off_boff, off_gw, off_aff, off_zero, floats_spec, floats_fused;
+  int32_t aff_stride;  // floats between the scale and the shift table: 64 or 128 (n_mels rounded up)
 };
 
 struct FrontParams {
@@ -72,7 +73,7 @@ struct FrontParams {
   int32_t span, span_blocks, dma, early, wave_floats, part_off;
   int32_t image_floats, off_queue, off_wave;
   ImageLayout im;
-  int32_t mel_sets, mel_u, mel_maxpos, n_quads, out_vec;
+  int32_t mel_sets, mel_u, mel_maxpos, n_quads, out_vec, aff_stride;
   unsigned long long* stamps;  // SED_TIMELINE builds only
 };
 
@@ -303,7 +304,7 @@ __device__ __forceinline__ void mel_mfma_one_burst(const int (&boff)[kMaxMelSets
   v4 a[Mel::SETS][Mel::U], bb[NG][Mel::SETS][Mel::U];
   static_for<0, Mel::SETS>([&](auto Sf) {
     constexpr int s = decltype(Sf)::value;
-    const float* ap = mela + ((size_t)s * (Mel::U + 1) * 64 + lane) * 4;
+    const float* ap = mela + ((size_t)s * Mel::U * 64 + lane) * 4;
     static_for<0, Mel::U>([&](auto Uf) {
       constexpr int u = decltype(Uf)::value;
       a[s][u] = ld4(ap + 256 * u);
@@ -333,8 +334,7 @@ __device__ __forceinline__ void mel_mfma_one_burst(const int (&boff)[kMaxMelSets
 // Mel projection of 4 frames (power rows prow0 + j*PITCH, j = 0..3) on the matrix pipe.
 // Lane 4*block + j feeds the power of frame j as the B operand and the weight of filter 4*quad + j as the
 // A operand of block `block`; after the last instruction it holds, in acc[i], the partial sum of filter
-// 4*quad + i for frame j over the bins of position (set, block).  The weight table carries one all-zero step per
-// set, so an odd step count needs no special case.  The partial sums go to LDS, kPartStride floats per slot; which
+// 4*quad + i for frame j over the bins of position (set, block).  The partial sums go to LDS, kPartStride floats per slot; which
 // slot a block fills comes from the lane's table word (blocks are placed for bank-conflict-free operand reads, slots
 // follow the quads).
 template <class Mel, int BURST_STEPS = 12>
@@ -346,7 +346,7 @@ __device__ __forceinline__ void mel_mfma_4frames(const FrontParams& p, const int
   int boff[kMaxMelSets];
   static_for<0, kMaxMelSets>([&](auto Sf) {
     constexpr int s = decltype(Sf)::value;
-    boff[s] = (!Mel::kStatic || s < Mel::SETS) ? boffL[s * 64 + lane] : 0;
+    boff[s] = (Mel::kStatic ? s < Mel::SETS : s < p.mel_sets) ? boffL[s * 64 + lane] : 0;
   });
 #ifndef SED_NO_MEL_ONE_BURST
   if constexpr (Mel::kStatic && Mel::SETS * Mel::U <= BURST_STEPS) {
@@ -363,7 +363,7 @@ __device__ __forceinline__ void mel_mfma_4frames(const FrontParams& p, const int
     constexpr int s = decltype(Sf)::value;
     if (s < sets) {
       const float* bp = prow0 + (boff[s] & 0xffff);
-      const float* ap = mela + ((size_t)s * (U + 1) * 64 + lane) * 4;
+      const float* ap = mela + ((size_t)s * U * 64 + lane) * 4;
       v4 acc = v4{0.0f, 0.0f, 0.0f, 0.0f};
       for (int u0 = 0; u0 < U; u0 += kMelBurst) {
         // one burst of LDS reads for up to kMelBurst steps of 4 bins, then the instructions, two steps per
@@ -374,7 +374,8 @@ __device__ __forceinline__ void mel_mfma_4frames(const FrontParams& p, const int
           if (u0 + k < U) {  // wave-uniform: pairs of steps past the end are not fetched at all
             a[k] = ld4(ap + 256 * (u0 + k));
             bb[k] = ld4(bp + 4 * (u0 + k));
-            a[k + 1] = ld4(ap + 256 * (u0 + k + 1));  // u0 + k + 1 == U reads the all-zero weights
+            a[k + 1] = ld4(ap + 256 * min(u0 + k + 1, U - 1));
+            if (u0 + k + 1 >= U) a[k + 1] = v4{0.0f, 0.0f, 0.0f, 0.0f};  // wave-uniform: an odd step count ends on zero weights
             bb[k + 1] = ld4(bp + 4 * min(u0 + k + 1, U - 1));
           }
         });
@@ -436,7 +437,7 @@ __device__ __forceinline__ v4 mel_gather_log(const FrontParams& p, const int32_t
     val.w = 0.6931471805599453f * __log2f(fmaxf(sum.w, p.amin));
   }
   const int m0 = 4 * (16 * r + (lane >> 2));
-  if (p.affine) val = __builtin_elementwise_fma(val, ld4(affL + m0), ld4(affL + 128 + m0));
+  if (p.affine) val = __builtin_elementwise_fma(val, ld4(affL + m0), ld4(affL + p.aff_stride + m0));
   return val;
 }
 
@@ -487,7 +488,7 @@ __device__ __forceinline__ v4 mel_gather_finish(const FrontParams& p, const floa
     val.w = 0.6931471805599453f * __log2f(fmaxf(sum.w, p.amin));
   }
   const int m0 = 4 * (16 * r + (lane >> 2));
-  if (p.affine) val = __builtin_elementwise_fma(val, ld4(affL + m0), ld4(affL + 128 + m0));
+  if (p.affine) val = __builtin_elementwise_fma(val, ld4(affL + m0), ld4(affL + p.aff_stride + m0));
   return val;
 }
 
@@ -992,10 +993,13 @@ static void build_image(sed_plan* pl) {
   im.off_tw2 = off; off += G::TW2_FLOATS;
   im.floats_spec = round4(off);
   off = im.floats_spec;
+  // per-lane words and affine tables are sized for the plan: sets actually used, one or two gather rounds, n_mels
+  const int rounds = sc.n_quads > 16 ? 2 : 1;
+  im.aff_stride = M <= 64 ? 64 : 128;
   im.off_mela = off; off += (int)sc.a.size();
-  im.off_boff = off; off += kMaxMelSets * 64;
-  im.off_gw = off; off += 2 * 64;
-  im.off_aff = off; off += 256;
+  im.off_boff = off; off += sc.sets * 64;
+  im.off_gw = off; off += rounds * 64;
+  im.off_aff = off; off += 2 * im.aff_stride;
   im.off_zero = off; off += 4;
   im.floats_fused = round4(off);
   std::vector<float> img(im.floats_fused, 0.0f);
@@ -1014,20 +1018,19 @@ static void build_image(sed_plan* pl) {
     }
   std::copy(sc.a.begin(), sc.a.end(), img.begin() + im.off_mela);
   int32_t* boff = reinterpret_cast<int32_t*>(img.data() + im.off_boff);
-  for (int s = 0; s < kMaxMelSets; ++s)
+  for (int s = 0; s < sc.sets; ++s)
     for (int ln = 0; ln < 64; ++ln)  // low half: the lane's first power value; high half: where its partial sums go
-      boff[s * 64 + ln] = s < sc.sets ? ((ln & 3) * G::PP + sc.base[s * 16 + (ln >> 2)]) |
-                                            ((sc.slot[s * 16 + (ln >> 2)] * kPartStride + (ln & 3) * 4) << 16)
-                                      : 0;
+      boff[s * 64 + ln] = ((ln & 3) * G::PP + sc.base[s * 16 + (ln >> 2)]) |
+                          ((sc.slot[s * 16 + (ln >> 2)] * kPartStride + (ln & 3) * 4) << 16);
   int32_t* gw = reinterpret_cast<int32_t*>(img.data() + im.off_gw);
-  for (int ol = 0; ol < 128; ++ol) {  // gather word of output lane ol: lane 4*quad + frame sums the partial sums of its quad
+  for (int ol = 0; ol < 64 * rounds; ++ol) {  // gather word of output lane ol: lane 4*quad + frame sums the partial sums of its quad
     const int q = ol >> 2, jj = ol & 3;
     // lanes without a quad read the zero block: offset of a position that holds finite values, zero positions beyond the first
     gw[ol] = q < sc.n_quads ? (((sc.quadpos[q] & 0xffff) * kPartStride + jj * 4) | ((sc.quadpos[q] >> 16) << 16)) : (1 << 16);
   }
-  for (int m = 0; m < 128; ++m) {
+  for (int m = 0; m < im.aff_stride; ++m) {
     img[im.off_aff + m] = (pl->affine && m < M) ? pl->scale_host[m] : 0.0f;
-    img[im.off_aff + 128 + m] = (pl->affine && m < M) ? pl->shift_host[m] : 0.0f;
+    img[im.off_aff + im.aff_stride + m] = (pl->affine && m < M) ? pl->shift_host[m] : 0.0f;
   }
   pl->im = im;
   pl->image_host.swap(img);
@@ -1229,13 +1232,14 @@ extern "C" int sed_plan_set_affine(sed_plan* pl, const float* scale, const float
     if (rc) return rc;
   }
   // Only the 256 affine floats of the LDS image change: the mel schedule and the other tables stay as they are.
-  if (!pl->d_image || pl->image_host.size() < (size_t)pl->im.off_aff + 256) return upload_tables(pl);
+  const int stride = pl->im.aff_stride;
+  if (!pl->d_image || stride < 1 || pl->image_host.size() < (size_t)pl->im.off_aff + 2 * stride) return upload_tables(pl);
   float* aff = pl->image_host.data() + pl->im.off_aff;
-  for (int m = 0; m < 128; ++m) {
+  for (int m = 0; m < stride; ++m) {
     aff[m] = (pl->affine && m < M) ? pl->scale_host[m] : 0.0f;
-    aff[128 + m] = (pl->affine && m < M) ? pl->shift_host[m] : 0.0f;
+    aff[stride + m] = (pl->affine && m < M) ? pl->shift_host[m] : 0.0f;
   }
-  return hip_status(hipMemcpy(pl->d_image + pl->im.off_aff, aff, 256 * sizeof(float), hipMemcpyHostToDevice));
+  return hip_status(hipMemcpy(pl->d_image + pl->im.off_aff, aff, 2 * stride * sizeof(float), hipMemcpyHostToDevice));
 }
 
 template <class G, bool MAG, bool SPEC_OUT, bool PRE, class Mel>
@@ -1247,7 +1251,15 @@ static int launch_front_shape(const sed_plan* pl, FrontParams p, int64_t B, hipS
   constexpr int SKEW = span_skew<G, Mel, PRE, SPEC_OUT>();
   // floats of the region an early span transfer writes: whole 1 KB blocks, or the skewed span exactly
   const int span_floats = SKEW > 0 ? skewed_floats(p.span, Mel::HOP, SKEW) : 256 * p.span_blocks;
+  // The partial sums of the mel stage normally sit behind the power rows.  When the operands of ALL matrix instructions
+  // of a group are fetched in one burst (the compiled-in shapes of 4-frame geometries), the power rows are dead by the time
+  // the partial sums are stored (the LDS serves a wavefront's accesses in order), so the sums may lie on top of them:
+  // right behind the area the next span's early transfer writes.
+  constexpr bool kOverlay = !SPEC_OUT && G::FPW == 4 && Mel::kStatic && Mel::SETS * Mel::U <= (G::NFFT == 2048 ? SED_BURST2048 : 12);
   p.part_off = std::max(G::FPW * G::PP, SKEW > 0 ? span_floats : 0);  // (a skewed span may reach past the power rows)
+#ifndef SED_NO_MEL_ONE_BURST
+  if (kOverlay && span_floats < G::FPW * G::PP) p.part_off = round64(span_floats);
+#endif
   p.early = p.dma && !SPEC_OUT && span_floats <= p.part_off;  // the span may land while the partial sums are in use
   const int part_floats = SPEC_OUT ? 0 : p.mel_sets * 16 * kPartStride;
   p.pre_off = 256 * p.span_blocks;  // behind the staged span: FPW frames x LPF partial sums (Kaldi DC removal)
@@ -1370,6 +1382,9 @@ static int launch_front(const sed_plan* pl, const FrontParams& p, int64_t B, hip
       return p.mel_sets == sets && p.mel_u == u && p.mel_maxpos == maxpos && two == rounds2;
     };
     if constexpr (G::NFFT == 1024 && !MAG && !PRE) {  // HTS-AT: Slaney 64 mel, 50..14000 Hz at 32 kHz
+#ifdef SED_EST_MEL_U  // timing experiments: a shorter chain per accumulator set than the plan's schedule has (results are then garbage)
+      if (is(2, 6, 5, false) && p.hop == 320) return launch_front_shape<G, MAG, SPEC_OUT, PRE, MelStatic<2, SED_EST_MEL_U, 5, 1, 320>>(pl, p, B, stream);
+#endif
       if (is(2, 6, 5, false) && p.hop == 320) return launch_front_shape<G, MAG, SPEC_OUT, PRE, MelStatic<2, 6, 5, 1, 320>>(pl, p, B, stream);
       if (is(2, 6, 5, false)) return launch_front_shape<G, MAG, SPEC_OUT, PRE, MelStatic<2, 6, 5, 1>>(pl, p, B, stream);
     }
@@ -1429,6 +1444,7 @@ static int front_forward(const sed_plan* pl, const void* pcm, int64_t B, int64_t
   p.mel_u = pl->mel_u;
   p.mel_maxpos = pl->mel_maxpos;
   p.n_quads = pl->n_quads;
+  p.aff_stride = pl->im.aff_stride;
   p.dma = (c.pcm_kind == SED_PCM_F32) && ((uintptr_t)pcm % 16 == 0) && (pcm_stride % 4 == 0) && (c.hop % 4 == 0) ? 1 : 0;  // n_fft/2: a multiple of 4
   if (SED_SKIP(2048)) p.dma = 0;  // experiment: register-staged spans for fp32 too
   p.out_vec = (c.n_mels % 4 == 0) && ((uintptr_t)out % 16 == 0) && (out_stride_b % 4 == 0) ? 1 : 0;

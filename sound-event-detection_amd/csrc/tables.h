@@ -195,7 +195,7 @@ struct MelMfmaSchedule {
   int tau = 0;         // bins per position, multiple of 4
   int n_quads = 0;
   int max_pos = 0;     // most positions any quad was cut into
-  std::vector<float> a;         // [set][tau/4 + 1][lane = 4*block + i][4]: weight of bin base+4u+e for mel 4*quad+i; the last step of a set is all zero
+  std::vector<float> a;         // [set][tau/4][lane = 4*block + i][4]: weight of bin base+4u+e for mel 4*quad+i
   std::vector<int32_t> base;    // [set][block]: first bin the position reads (multiple of 4, base + tau <= row_pitch)
   std::vector<int32_t> slot;    // [set][block]: where the block's partial sums go (positions in quad order; unused blocks behind them)
   std::vector<int32_t> quadpos; // [quad]: first slot | (number of positions << 16); a quad's slots are consecutive
@@ -228,7 +228,7 @@ inline MelMfmaSchedule schedule_mel_mfma(const std::vector<float>& melW, int F, 
   sc.sets = best_sets;
   sc.tau = std::min(best_tau, row_pitch / 4 * 4);
   const int P = 16 * sc.sets, U = sc.tau / 4;
-  sc.a.assign((size_t)sc.sets * (U + 1) * 64 * 4, 0.0f);
+  sc.a.assign((size_t)sc.sets * U * 64 * 4, 0.0f);
   sc.base.assign(P, 0);
   sc.slot.assign(P, 0);
   // Positions in quad order (= the order of their partial-sum slots), then their places (set, block).  The 16 lanes the
@@ -272,7 +272,7 @@ inline MelMfmaSchedule schedule_mel_mfma(const std::vector<float>& melW, int F, 
       const int k = base + t;
       if (k < seg_lo || k >= seg_hi || k >= F) continue;
       for (int i = 0; i < 4 && 4 * q + i < M; ++i)
-        sc.a[(((size_t)set * (U + 1) + t / 4) * 64 + 4 * block + i) * 4 + t % 4] = melW[(size_t)k * M + 4 * q + i];
+        sc.a[(((size_t)set * U + t / 4) * 64 + 4 * block + i) * 4 + t % 4] = melW[(size_t)k * M + 4 * q + i];
     }
   }
   for (const auto& v : of_quad) sc.max_pos = std::max(sc.max_pos, (int)v.size());

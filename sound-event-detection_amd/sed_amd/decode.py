@@ -19,7 +19,6 @@ from __future__ import annotations
 
 import itertools
 import json
-import operator
 import os
 from typing import Any, Dict, List, Sequence
 
@@ -30,7 +29,6 @@ from . import _lib as L
 
 CLASSES = ["cough", "dog_bark", "gun_shot", "siren", "car_horn"]           # src/config.py:4
 NON_EVENT_LABEL = "non_event"                                               # src/models/htsat/constants.py:8
-_EVENT_FIELDS = operator.itemgetter("event_onset", "event_offset", "event_label")
 _SMOOTH = {None: L.SMOOTH_NONE, "none": L.SMOOTH_NONE, "median3": L.SMOOTH_MEDIAN3, "gauss": L.SMOOTH_GAUSS25}
 
 
@@ -325,11 +323,11 @@ def merge_close_events_batch(events_by_file: Dict[str, List[Dict[str, Any]]], th
     if n == 0:
         outs = [{k: [] for k in keys} for _ in gaps]
         return outs if many else outs[0]
-    cols = list(zip(*map(_EVENT_FIELDS, flat)))
-    on = np.array(cols[0], dtype=np.float64)
-    off = np.array(cols[1], dtype=np.float64)
-    ids = {lbl: i for i, lbl in enumerate(dict.fromkeys(cols[2]))}
-    lab = np.array(list(map(ids.__getitem__, cols[2])), dtype=np.int64)
+    on = np.array([ev["event_onset"] for ev in flat], dtype=np.float64)
+    off = np.array([ev["event_offset"] for ev in flat], dtype=np.float64)
+    labels = [ev["event_label"] for ev in flat]
+    ids = {lbl: i for i, lbl in enumerate(dict.fromkeys(labels))}
+    lab = np.array(list(map(ids.__getitem__, labels)), dtype=np.int64)
     file_idx = np.repeat(np.arange(len(keys)), lens)
     # events of a file in onset order (stable), then the (file, label) groups in the order their first event appears
     by_onset = np.lexsort((on, file_idx))
