@@ -117,24 +117,25 @@ double run_conditioned(unsigned seed, int win_length, float coef) {
 }
 
 // Emulates the MFMA mel projection from its schedule tables and compares with the dense product.
-static double check_mel_schedule(int sr, int n_fft, int M, double fmin, double fmax, bool htk, int pitch) {
-  const int F = n_fft / 2 + 1;
-  const std::vector<float> W = htk ? mel_htk_tf(sr, n_fft, M, fmin, fmax) : mel_slaney(sr, n_fft, M, fmin, fmax);
+static double check_mel_schedule(int sr, int n_fft, int M, double fmin, double fmax, int kind, int pitch) {
+  const int F = n_fft / 2 + 1;  // kind 0: Slaney (librosa), 1: HTK (TensorFlow), 2: Kaldi
+  const std::vector<float> W = kind == 2 ? mel_kaldi(sr, n_fft, M, fmin, fmax)
+                               : kind == 1 ? mel_htk_tf(sr, n_fft, M, fmin, fmax) : mel_slaney(sr, n_fft, M, fmin, fmax);
   const MelMfmaSchedule sc = schedule_mel_mfma(W, F, M, pitch);
   std::mt19937 rng(5);
   std::uniform_real_distribution<float> ud(0.0f, 1.0f);
   std::vector<float> pw(4 * pitch, 0.0f);
   for (int j = 0; j < 4; ++j)
     for (int k = 0; k < F; ++k) pw[j * pitch + k] = ud(rng) * (k < 40 ? 100.0f : 1.0f);
-  const int U = sc.tau / 4;
   std::vector<double> part((size_t)16 * sc.sets * 16, 0.0);  // [position][i][j]
   for (int set = 0; set < sc.sets; ++set)
-    for (int u = 0; u < U; ++u)
+    for (int u = 0; u < sc.steps_of(set); ++u)
       for (int e = 0; e < 4; ++e)
         for (int block = 0; block < 16; ++block)
           for (int i = 0; i < 4; ++i)
             for (int j = 0; j < 4; ++j) {
-              const float a = sc.a[(((size_t)set * U + u) * 64 + 4 * block + i) * 4 + e];
+              const float a = sc.a[(size_t)sc.a_offset(set) + ((size_t)u * 64 + 4 * block + i) * 4 + e];
+              if (sc.base[set * 16 + block] + 4 * u + e >= pitch) { std::printf("position reads past the row\n"); return 1.0; }
               const float b = pw[j * pitch + sc.base[set * 16 + block] + 4 * u + e];
               part[((size_t)sc.slot[set * 16 + block] * 4 + i) * 4 + j] += (double)a * b;
             }
@@ -147,19 +148,22 @@ static double check_mel_schedule(int sr, int n_fft, int M, double fmin, double f
       for (int k = 0; k < F; ++k) want += (double)W[(size_t)k * M + m] * pw[j * pitch + k];
       worst = std::max(worst, std::fabs(got - want) / std::max(1e-30, std::fabs(want)));
     }
-  std::printf("mel schedule n_fft=%d M=%d sets=%d tau=%d instr=%d max_pos=%d rel_err %.2e\n", n_fft, M, sc.sets, sc.tau,
-              sc.sets * sc.tau, sc.max_pos, worst);
+  std::printf("mel schedule n_fft=%d M=%d sets=%d steps %d x %d + %d x %d instr=%d max_pos=%d rel_err %.2e\n", n_fft, M, sc.sets,
+              sc.n_hi, sc.u_hi, sc.sets - sc.n_hi, sc.u_lo, 4 * sc.total_steps(), sc.max_pos, worst);
   return worst;
 }
 
 int main() {
   int bad = 0;
-  if (check_mel_schedule(32000, 1024, 64, 50, 14000, false, 516) > 1e-12) bad = 1;
-  if (check_mel_schedule(16000, 512, 64, 125, 7500, true, 260) > 1e-12) bad = 1;
-  if (check_mel_schedule(44100, 2048, 40, 0, 22050, false, 1028) > 1e-12) bad = 1;
-  if (check_mel_schedule(44100, 2048, 64, 0, 22050, false, 1028) > 1e-12) bad = 1;
-  if (check_mel_schedule(44100, 2048, 128, 0, 22050, false, 1028) > 1e-12) bad = 1;
-  if (check_mel_schedule(8000, 512, 3, 100, 3000, false, 260) > 1e-12) bad = 1;
+  if (check_mel_schedule(32000, 1024, 64, 50, 14000, 0, 516) > 1e-12) bad = 1;
+  if (check_mel_schedule(16000, 512, 64, 125, 7500, 1, 260) > 1e-12) bad = 1;
+  if (check_mel_schedule(44100, 2048, 40, 0, 22050, 0, 1028) > 1e-12) bad = 1;
+  if (check_mel_schedule(44100, 2048, 64, 0, 22050, 0, 1028) > 1e-12) bad = 1;
+  if (check_mel_schedule(44100, 2048, 128, 0, 22050, 0, 1028) > 1e-12) bad = 1;
+  if (check_mel_schedule(8000, 512, 3, 100, 3000, 0, 260) > 1e-12) bad = 1;
+  if (check_mel_schedule(16000, 512, 128, 20, 0, 2, 260) > 1e-12) bad = 1;
+  if (check_mel_schedule(32000, 1024, 128, 0, 16000, 0, 516) > 1e-12) bad = 1;
+  if (check_mel_schedule(22050, 2048, 17, 300, 9000, 1, 1028) > 1e-12) bad = 1;
   auto report = [&](int n_fft, const char* what, double e) {
     std::printf("%d %s max_rel_err %.3e\n", n_fft, what, e);
     if (!(e < 2e-6)) bad = 1;

@@ -73,7 +73,7 @@ struct FrontParams {
   int32_t span, span_blocks, dma, early, wave_floats, part_off;
   int32_t image_floats, off_queue, off_wave;
   ImageLayout im;
-  int32_t mel_sets, mel_u, mel_maxpos, n_quads, out_vec, aff_stride;
+  int32_t mel_sets, mel_u, mel_ulo, mel_nhi, mel_maxpos, n_quads, out_vec, aff_stride;
   unsigned long long* stamps;  // SED_TIMELINE builds only
 };
 
@@ -266,15 +266,21 @@ __device__ __forceinline__ void stage_span_dma_skewed(const FrontParams& p, floa
 // Shape of a plan's mel schedule.  The shapes of the reference's own flavours are compiled in, which turns the
 // loops over accumulator sets, steps and positions into straight-line code; any other filterbank runs the same code with
 // the shape read from the launch parameters.
-template <int SETS_, int U_, int MAXPOS_, int ROUNDS_, int HOP_ = 0>
+// Accumulator sets [0, NHI) run U steps of 4 bins, sets [NHI, SETS) run ULO <= U steps (see MelMfmaSchedule).
+template <int SETS_, int U_, int MAXPOS_, int ROUNDS_, int HOP_ = 0, int ULO_ = U_, int NHI_ = SETS_>
 struct MelStatic {
   static constexpr bool kStatic = true;
-  static constexpr int SETS = SETS_, U = U_, MAXPOS = MAXPOS_, ROUNDS = ROUNDS_;
+  static constexpr int SETS = SETS_, U = U_, MAXPOS = MAXPOS_, ROUNDS = ROUNDS_, ULO = ULO_, NHI = NHI_;
   static constexpr int HOP = HOP_;  // the flavour's hop when it is compiled in too (0: read from the launch parameters)
+  static constexpr int STEPS = NHI * U + (SETS - NHI) * ULO;  // steps of all sets together
+  static constexpr int steps(int s) { return s < NHI ? U : ULO; }
+  static constexpr int a_offset(int s) { return 256 * ((s < NHI ? s : NHI) * U + (s > NHI ? s - NHI : 0) * ULO); }  // floats
 };
 struct MelDynamic {
   static constexpr bool kStatic = false;
-  static constexpr int SETS = 0, U = 0, MAXPOS = 0, ROUNDS = 0, HOP = 0;
+  static constexpr int SETS = 0, U = 0, MAXPOS = 0, ROUNDS = 0, HOP = 0, ULO = 0, NHI = 0, STEPS = 1 << 20;
+  static constexpr int steps(int) { return 0; }
+  static constexpr int a_offset(int) { return 0; }
 };
 
 // Skew of the staged span, in floats per hop.  With 16 lanes per frame the LDS serves the sample reads of two frames
@@ -290,12 +296,19 @@ constexpr int span_skew() {
 // floats of LDS a skewed span of `span` samples takes
 constexpr int skewed_floats(int span, int hop, int skew) { return (span + skew * ((span - 1) / hop) + 3) & ~3; }
 template <class Mel> __device__ __forceinline__ int mel_sets_of(const FrontParams& p) { if constexpr (Mel::kStatic) return Mel::SETS; else return p.mel_sets; }
-template <class Mel> __device__ __forceinline__ int mel_u_of(const FrontParams& p) { if constexpr (Mel::kStatic) return Mel::U; else return p.mel_u; }
+// steps of accumulator set s and where its weights start in the A-operand table (floats)
+template <class Mel> __device__ __forceinline__ int mel_steps_of(const FrontParams& p, int s) {
+  if constexpr (Mel::kStatic) return Mel::steps(s); else return s < p.mel_nhi ? p.mel_u : p.mel_ulo;
+}
+template <class Mel> __device__ __forceinline__ int mel_aoff_of(const FrontParams& p, int s) {
+  if constexpr (Mel::kStatic) return Mel::a_offset(s);
+  else return 256 * (min(s, p.mel_nhi) * p.mel_u + max(0, s - p.mel_nhi) * p.mel_ulo);
+}
 template <class Mel> __device__ __forceinline__ int mel_maxpos_of(const FrontParams& p) { if constexpr (Mel::kStatic) return Mel::MAXPOS; else return p.mel_maxpos; }
 template <class Mel> __device__ __forceinline__ bool mel_two_rounds(const FrontParams& p) { if constexpr (Mel::kStatic) return Mel::ROUNDS > 1; else return p.n_quads > 16; }
 
 // Small compiled-in shapes: the operands of all accumulator sets (and of NG groups of 4 frames, `gpitch` floats apart)
-// are fetched in ONE burst of 2 * NG * SETS * U 16-byte reads (the transform registers are free by now), so the stage
+// are fetched in ONE burst of 2 * NG * STEPS 16-byte reads (the transform registers are free by now), so the stage
 // waits for the LDS once instead of once per set and group, and the instructions of the chains alternate, which also
 // leaves no dependent pair back to back.  acc[g][s]: partial sums of set s for group g, as mel_mfma_4frames stores them.
 template <class Mel, int NG>
@@ -304,8 +317,8 @@ __device__ __forceinline__ void mel_mfma_one_burst(const int (&boff)[kMaxMelSets
   v4 a[Mel::SETS][Mel::U], bb[NG][Mel::SETS][Mel::U];
   static_for<0, Mel::SETS>([&](auto Sf) {
     constexpr int s = decltype(Sf)::value;
-    const float* ap = mela + ((size_t)s * Mel::U * 64 + lane) * 4;
-    static_for<0, Mel::U>([&](auto Uf) {
+    const float* ap = mela + Mel::a_offset(s) + lane * 4;
+    static_for<0, Mel::steps(s)>([&](auto Uf) {
       constexpr int u = decltype(Uf)::value;
       a[s][u] = ld4(ap + 256 * u);
       static_for<0, NG>([&](auto Gf) {
@@ -324,7 +337,7 @@ __device__ __forceinline__ void mel_mfma_one_burst(const int (&boff)[kMaxMelSets
         constexpr int g = decltype(Gf)::value;
         static_for<0, Mel::SETS>([&](auto Sf) {
           constexpr int s = decltype(Sf)::value;
-          acc[g][s] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[s][u][e], bb[g][s][u][e], acc[g][s], 0, 0, 0);
+          if constexpr (u < Mel::steps(s)) acc[g][s] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[s][u][e], bb[g][s][u][e], acc[g][s], 0, 0, 0);
         });
       });
     });
@@ -341,7 +354,6 @@ template <class Mel, int BURST_STEPS = 12>
 __device__ __forceinline__ void mel_mfma_4frames(const FrontParams& p, const int32_t* boffL, const float* prow0,
                                                  const float* mela, float* part, int lane) {
   asm volatile("" : "+v"(lane));  // keeps the per-lane table reads inside the streaming loop instead of pinning registers
-  const int U = mel_u_of<Mel>(p);
   const int sets = SED_SKIP(32) ? 0 : mel_sets_of<Mel>(p);
   int boff[kMaxMelSets];
   static_for<0, kMaxMelSets>([&](auto Sf) {
@@ -349,7 +361,7 @@ __device__ __forceinline__ void mel_mfma_4frames(const FrontParams& p, const int
     boff[s] = (Mel::kStatic ? s < Mel::SETS : s < p.mel_sets) ? boffL[s * 64 + lane] : 0;
   });
 #ifndef SED_NO_MEL_ONE_BURST
-  if constexpr (Mel::kStatic && Mel::SETS * Mel::U <= BURST_STEPS) {
+  if constexpr (Mel::kStatic && Mel::STEPS <= BURST_STEPS) {
     if (!SED_SKIP(32)) {
       v4 acc[1][Mel::SETS];
       mel_mfma_one_burst<Mel, 1>(boff, prow0, 0, mela, acc, lane);
@@ -363,7 +375,8 @@ __device__ __forceinline__ void mel_mfma_4frames(const FrontParams& p, const int
     constexpr int s = decltype(Sf)::value;
     if (s < sets) {
       const float* bp = prow0 + (boff[s] & 0xffff);
-      const float* ap = mela + ((size_t)s * U * 64 + lane) * 4;
+      const int U = mel_steps_of<Mel>(p, s);
+      const float* ap = mela + mel_aoff_of<Mel>(p, s) + lane * 4;
       v4 acc = v4{0.0f, 0.0f, 0.0f, 0.0f};
       for (int u0 = 0; u0 < U; u0 += kMelBurst) {
         // one burst of LDS reads for up to kMelBurst steps of 4 bins, then the instructions, two steps per
@@ -680,7 +693,7 @@ stft_mel_kernel(const FrontParams p) {
       } else {
         float* part = X + p.part_off;
 #ifndef SED_NO_MEL_ONE_BURST
-        if constexpr (kGroups == 2 && Mel::kStatic && 2 * Mel::SETS * Mel::U <= 16) {
+        if constexpr (kGroups == 2 && Mel::kStatic && 2 * Mel::STEPS <= 16) {
           // Both groups of 4 frames in one pass: one burst of operand reads, then the partial sums of the first group,
           // its gather reads, the partial sums of the second group (the LDS executes a wavefront's accesses in order, so
           // they may reuse the area) and its gather reads, and one wait for all of them.
@@ -946,7 +959,7 @@ struct sed_plan {
   std::vector<float> image_host;
   float* d_image = nullptr;
   ImageLayout im{};
-  int mel_sets = 0, mel_u = 0, mel_maxpos = 0, n_quads = 0;
+  int mel_sets = 0, mel_u = 0, mel_ulo = 0, mel_nhi = 0, mel_maxpos = 0, n_quads = 0;
   // banded mel matrix scheduled over 16 lanes (mel_rows_kernel)
   MelEntry* d_meta16 = nullptr;
   float* d_melw16 = nullptr;
@@ -984,7 +997,9 @@ static void build_image(sed_plan* pl) {
   const int F = pl->cfg.n_fft / 2 + 1, M = pl->cfg.n_mels;
   const MelMfmaSchedule sc = schedule_mel_mfma(pl->melW_host, F, M, G::PP, kMaxMelSets);
   pl->mel_sets = sc.sets;
-  pl->mel_u = sc.tau / 4;
+  pl->mel_u = sc.u_hi;
+  pl->mel_ulo = sc.u_lo;
+  pl->mel_nhi = sc.n_hi;
   pl->mel_maxpos = sc.max_pos;
   pl->n_quads = sc.n_quads;
   ImageLayout im{};
@@ -1255,7 +1270,7 @@ static int launch_front_shape(const sed_plan* pl, FrontParams p, int64_t B, hipS
   // of a group are fetched in one burst (the compiled-in shapes of 4-frame geometries), the power rows are dead by the time
   // the partial sums are stored (the LDS serves a wavefront's accesses in order), so the sums may lie on top of them:
   // right behind the area the next span's early transfer writes.
-  constexpr bool kOverlay = !SPEC_OUT && G::FPW == 4 && Mel::kStatic && Mel::SETS * Mel::U <= (G::NFFT == 2048 ? SED_BURST2048 : 12);
+  constexpr bool kOverlay = !SPEC_OUT && G::FPW == 4 && Mel::kStatic && Mel::STEPS <= (G::NFFT == 2048 ? SED_BURST2048 : 12);
   p.part_off = std::max(G::FPW * G::PP, SKEW > 0 ? span_floats : 0);  // (a skewed span may reach past the power rows)
 #ifndef SED_NO_MEL_ONE_BURST
   if (kOverlay && span_floats < G::FPW * G::PP) p.part_off = round64(span_floats);
@@ -1378,27 +1393,28 @@ static int launch_front(const sed_plan* pl, const FrontParams& p, int64_t B, hip
   constexpr bool PRE = PRE_;
   if constexpr (!SPEC_OUT) {
     const bool two = p.n_quads > 16;
-    auto is = [&](int sets, int u, int maxpos, bool rounds2) {
-      return p.mel_sets == sets && p.mel_u == u && p.mel_maxpos == maxpos && two == rounds2;
+    // (sets, steps of the first n_hi sets, steps of the others, n_hi, most positions per quad, two gather rounds)
+    auto is = [&](int sets, int u, int ulo, int nhi, int maxpos, bool rounds2) {
+      return p.mel_sets == sets && p.mel_u == u && p.mel_ulo == ulo && p.mel_nhi == nhi && p.mel_maxpos == maxpos && two == rounds2;
     };
     if constexpr (G::NFFT == 1024 && !MAG && !PRE) {  // HTS-AT: Slaney 64 mel, 50..14000 Hz at 32 kHz
 #ifdef SED_EST_MEL_U  // timing experiments: a shorter chain per accumulator set than the plan's schedule has (results are then garbage)
-      if (is(2, 6, 5, false) && p.hop == 320) return launch_front_shape<G, MAG, SPEC_OUT, PRE, MelStatic<2, SED_EST_MEL_U, 5, 1, 320>>(pl, p, B, stream);
+      if (is(2, 6, 4, 1, 5, false) && p.hop == 320) return launch_front_shape<G, MAG, SPEC_OUT, PRE, MelStatic<2, SED_EST_MEL_U, 5, 1, 320>>(pl, p, B, stream);
 #endif
-      if (is(2, 6, 5, false) && p.hop == 320) return launch_front_shape<G, MAG, SPEC_OUT, PRE, MelStatic<2, 6, 5, 1, 320>>(pl, p, B, stream);
-      if (is(2, 6, 5, false)) return launch_front_shape<G, MAG, SPEC_OUT, PRE, MelStatic<2, 6, 5, 1>>(pl, p, B, stream);
+      if (is(2, 6, 4, 1, 5, false) && p.hop == 320) return launch_front_shape<G, MAG, SPEC_OUT, PRE, MelStatic<2, 6, 5, 1, 320, 4, 1>>(pl, p, B, stream);
+      if (is(2, 6, 4, 1, 5, false)) return launch_front_shape<G, MAG, SPEC_OUT, PRE, MelStatic<2, 6, 5, 1, 0, 4, 1>>(pl, p, B, stream);
     }
     if constexpr (G::NFFT == 512 && MAG && !PRE) {  // YAMNet: HTK 64 mel, 125..7500 Hz at 16 kHz
-      if (is(2, 3, 4, false)) return launch_front_shape<G, MAG, SPEC_OUT, PRE, MelStatic<2, 3, 4, 1>>(pl, p, B, stream);
+      if (is(2, 4, 2, 1, 3, false)) return launch_front_shape<G, MAG, SPEC_OUT, PRE, MelStatic<2, 4, 3, 1, 0, 2, 1>>(pl, p, B, stream);
     }
     if constexpr (G::NFFT == 2048 && MAG && !PRE) {  // CRNN: Slaney 40 mel, 0..22050 Hz at 44.1 kHz
-      if (is(3, 7, 15, false)) return launch_front_shape<G, MAG, SPEC_OUT, PRE, MelStatic<3, 7, 15, 1>>(pl, p, B, stream);
+      if (is(3, 14, 3, 1, 9, false)) return launch_front_shape<G, MAG, SPEC_OUT, PRE, MelStatic<3, 14, 9, 1, 0, 3, 1>>(pl, p, B, stream);
     }
     if constexpr (G::NFFT == 2048 && !MAG && !PRE) {  // dB mel: Slaney 64 mel, 0..22050 Hz at 44.1 kHz
-      if (is(3, 8, 9, false)) return launch_front_shape<G, MAG, SPEC_OUT, PRE, MelStatic<3, 8, 9, 1>>(pl, p, B, stream);
+      if (is(3, 11, 5, 1, 7, false)) return launch_front_shape<G, MAG, SPEC_OUT, PRE, MelStatic<3, 11, 7, 1, 0, 5, 1>>(pl, p, B, stream);
     }
     if constexpr (G::NFFT == 512 && !MAG && PRE) {  // Kaldi fbank: 128 mel, 20..8000 Hz at 16 kHz
-      if (is(4, 2, 4, true)) return launch_front_shape<G, MAG, SPEC_OUT, PRE, MelStatic<4, 2, 4, 2>>(pl, p, B, stream);
+      if (is(3, 3, 2, 1, 3, true)) return launch_front_shape<G, MAG, SPEC_OUT, PRE, MelStatic<3, 3, 3, 2, 0, 2, 1>>(pl, p, B, stream);
     }
   }
   return launch_front_shape<G, MAG, SPEC_OUT, PRE, MelDynamic>(pl, p, B, stream);
@@ -1442,6 +1458,8 @@ static int front_forward(const sed_plan* pl, const void* pcm, int64_t B, int64_t
   p.inv_win_length = 1.0f / (float)c.win_length;
   p.mel_sets = pl->mel_sets;
   p.mel_u = pl->mel_u;
+  p.mel_ulo = pl->mel_ulo;
+  p.mel_nhi = pl->mel_nhi;
   p.mel_maxpos = pl->mel_maxpos;
   p.n_quads = pl->n_quads;
   p.aff_stride = pl->im.aff_stride;

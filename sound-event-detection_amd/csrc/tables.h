@@ -188,76 +188,153 @@ inline MelSchedule schedule_mel(const std::vector<float>& melW, int F, int M, in
 // ---- mel projection on the 4x4x1 16-block f32 MFMA -------------------------------------------------
 // One v_mfma_f32_4x4x1_16b_f32 multiplies, in each of its 16 blocks, 4 filter weights (one bin, 4
 // consecutive mel filters = a "quad") by the powers of that bin in 4 frames.  A "position" is one block
-// of one accumulator set; it owns a segment of at most tau consecutive bins of one quad.  Long quads are
-// cut into several positions so that all positions finish after the same number of instructions.
+// of one accumulator set; it owns a segment of consecutive bins of one quad.  Long quads are cut into
+// several positions.  All positions of a set run the same number of steps (4 bins each); the first n_hi
+// sets run u_hi steps, the others u_lo <= u_hi, so that short quads do not cost as many instructions as
+// the pieces of long ones (HTS-AT: 6 + 4 steps instead of 6 + 6).
 struct MelMfmaSchedule {
   int sets = 0;        // accumulator sets (4 VGPRs each); positions = 16 * sets
-  int tau = 0;         // bins per position, multiple of 4
+  int tau = 0;         // bins per position of the long sets (= 4 * u_hi)
+  int u_hi = 0, u_lo = 0, n_hi = 0;  // steps of sets [0, n_hi) and of sets [n_hi, sets)
   int n_quads = 0;
   int max_pos = 0;     // most positions any quad was cut into
-  std::vector<float> a;         // [set][tau/4][lane = 4*block + i][4]: weight of bin base+4u+e for mel 4*quad+i
-  std::vector<int32_t> base;    // [set][block]: first bin the position reads (multiple of 4, base + tau <= row_pitch)
+  std::vector<float> a;         // [set][steps of the set][lane = 4*block + i][4]: weight of bin base+4u+e for mel 4*quad+i
+  std::vector<int32_t> base;    // [set][block]: first bin the position reads (multiple of 4, base + 4 * steps <= row_pitch)
   std::vector<int32_t> slot;    // [set][block]: where the block's partial sums go (positions in quad order; unused blocks behind them)
   std::vector<int32_t> quadpos; // [quad]: first slot | (number of positions << 16); a quad's slots are consecutive
+  int steps_of(int set) const { return set < n_hi ? u_hi : u_lo; }
+  int a_offset(int set) const { return 256 * (std::min(set, n_hi) * u_hi + std::max(0, set - n_hi) * u_lo); }  // floats
+  int total_steps() const { return n_hi * u_hi + (sets - n_hi) * u_lo; }
 };
+
+// Cuts quads of n[q] steps into pieces of at most u_hi steps (at most cnt_hi of them) and of at most u_lo steps (at most
+// cnt_lo), no quad into more than max_pieces: a_out[q] long and b_out[q] short pieces, or false.  Exact (dynamic
+// programme over the quads: fewest short pieces for every number of long pieces used so far).
+inline bool mel_cut_quads(const std::vector<int>& n, int u_hi, int cnt_hi, int u_lo, int cnt_lo, int max_pieces,
+                          std::vector<int>* a_out, std::vector<int>* b_out) {
+  const int Q = (int)n.size(), INF = 1 << 28;
+  std::vector<std::vector<int>> best(Q + 1, std::vector<int>(cnt_hi + 1, INF)), choice(Q + 1, std::vector<int>(cnt_hi + 1, -1));
+  best[0][0] = 0;
+  for (int q = 0; q < Q; ++q)
+    for (int h = 0; h <= cnt_hi; ++h) {
+      if (best[q][h] >= INF) continue;
+      const int need = std::max(1, n[q]);
+      for (int a = 0; a <= std::min(max_pieces, cnt_hi - h); ++a) {
+        const int rem = need - a * u_hi;
+        int b = rem > 0 ? (u_lo > 0 ? (rem + u_lo - 1) / u_lo : INF) : 0;
+        if (a + b == 0) b = 1;
+        if (b >= INF || a + b > max_pieces) { if (rem <= 0) break; continue; }
+        if (best[q][h] + b < best[q + 1][h + a]) { best[q + 1][h + a] = best[q][h] + b; choice[q + 1][h + a] = a; }
+        if (rem <= 0) break;
+      }
+    }
+  int h = -1;
+  for (int k = 0; k <= cnt_hi; ++k)
+    if (best[Q][k] <= cnt_lo && (h < 0 || best[Q][k] < best[Q][h])) h = k;
+  if (h < 0) return false;
+  a_out->assign(Q, 0);
+  b_out->assign(Q, 0);
+  for (int q = Q; q > 0; --q) {
+    const int a = choice[q][h];
+    (*a_out)[q - 1] = a;
+    (*b_out)[q - 1] = best[q][h] - best[q - 1][h - a];
+    h -= a;
+  }
+  return true;
+}
 
 inline MelMfmaSchedule schedule_mel_mfma(const std::vector<float>& melW, int F, int M, int row_pitch, int max_sets = 4) {
   MelMfmaSchedule sc;
   const int NQ = (M + 3) / 4;
   sc.n_quads = NQ;
-  std::vector<int> lo(NQ, 0), len(NQ, 0);
+  std::vector<int> lo(NQ, 0), len(NQ, 0), steps(NQ, 0);
   for (int q = 0; q < NQ; ++q) {
     int a = F, b = -1;
     for (int k = 0; k < F; ++k)
       for (int i = 0; i < 4 && 4 * q + i < M; ++i)
         if (melW[(size_t)k * M + 4 * q + i] != 0.0f) { a = std::min(a, k); b = std::max(b, k); }
     if (b >= a) { lo[q] = a / 4 * 4; len[q] = (b + 1 - lo[q] + 3) / 4 * 4; }
+    steps[q] = len[q] / 4;
   }
-  auto positions_needed = [&](int tau) {
-    int n = 0;
-    for (int q = 0; q < NQ; ++q) n += std::max(1, (len[q] + tau - 1) / tau);
-    return n;
-  };
-  int best_sets = 0, best_tau = 0;
-  for (int s = 1; s <= max_sets; ++s) {
-    if (16 * s < NQ) continue;
-    int tau = 4;
-    while (positions_needed(tau) > 16 * s) tau += 4;
-    if (best_sets == 0 || s * tau < best_sets * best_tau) { best_sets = s; best_tau = tau; }
+  // Fewest instructions first (4 per step and set), then fewest positions per quad (gather reads), then fewest sets.
+  // Total steps are tried in ascending order from the bound 16 * total >= sum of steps; for one total every split into
+  // n_hi sets of u_hi and the rest of u_lo < u_hi steps (or all sets alike) is tested with the exact cutter.
+  const int max_u = std::max(1, row_pitch / 4);
+  int sum_steps = 0, longest = 1;
+  for (int q = 0; q < NQ; ++q) { sum_steps += std::max(1, steps[q]); longest = std::max(longest, steps[q]); }
+  std::vector<int> cut_a, cut_b;
+  bool found = false;
+  for (int total = std::max(1, (sum_steps + 15) / 16); !found && total <= max_sets * std::min(longest, max_u); ++total) {
+    int best_pos = 1 << 28, best_sets = 0;
+    for (int s = 1; s <= max_sets; ++s) {
+      if (16 * s < NQ) continue;
+      for (int n_hi = 1; n_hi <= s; ++n_hi)
+        for (int u_hi = 1; u_hi <= std::min(longest, max_u); ++u_hi) {
+          const int rest = total - n_hi * u_hi;
+          int u_lo;
+          if (n_hi == s) { if (rest != 0) continue; u_lo = u_hi; }
+          else { if (rest <= 0 || rest % (s - n_hi) != 0) continue; u_lo = rest / (s - n_hi); if (u_lo >= u_hi) continue; }
+          for (int pieces = 1; pieces <= 16 && pieces <= best_pos; ++pieces) {
+            std::vector<int> a, b;
+            if (!mel_cut_quads(steps, u_hi, 16 * n_hi, u_lo, n_hi == s ? 0 : 16 * (s - n_hi), pieces, &a, &b)) continue;
+            if (pieces < best_pos || (pieces == best_pos && s < best_sets)) {
+              best_pos = pieces; best_sets = s;
+              sc.sets = s; sc.n_hi = n_hi; sc.u_hi = u_hi; sc.u_lo = u_lo;
+              cut_a = a; cut_b = b;
+              found = true;
+            }
+            break;
+          }
+        }
+    }
   }
-  sc.sets = best_sets;
-  sc.tau = std::min(best_tau, row_pitch / 4 * 4);
-  const int P = 16 * sc.sets, U = sc.tau / 4;
-  sc.a.assign((size_t)sc.sets * U * 64 * 4, 0.0f);
+  if (!found) {  // (cannot happen for max_sets * 16 >= NQ: one long piece per quad always fits)
+    sc.sets = max_sets; sc.n_hi = max_sets; sc.u_hi = sc.u_lo = std::min(longest, max_u);
+    mel_cut_quads(steps, sc.u_hi, 16 * max_sets, sc.u_lo, 0, 16, &cut_a, &cut_b);
+  }
+  sc.tau = 4 * sc.u_hi;
+  const int P = 16 * sc.sets;
+  sc.a.assign((size_t)256 * sc.total_steps(), 0.0f);
   sc.base.assign(P, 0);
   sc.slot.assign(P, 0);
   // Positions in quad order (= the order of their partial-sum slots), then their places (set, block).  The 16 lanes the
   // LDS serves together when the power values are fetched are 4 consecutive blocks x 4 frames, frame rows 16 banks
   // apart, 4 banks per lane: they fall on distinct banks when the first bins of the 4 blocks differ mod 16 in their
   // multiple of 4.  So the positions are dealt out to the groups of 4 blocks like cards, sorted by that residue: every
-  // group gets its even share of each residue (all four when the filterbank offers them).
-  struct Pos { int quad, seg_lo, seg_hi, base; };
+  // group gets its even share of each residue (all four when the filterbank offers them).  Long pieces go to the long
+  // sets, short ones to the short sets.
+  struct Pos { int quad, seg_lo, seg_hi, base, is_hi; };
   std::vector<Pos> pos;
   std::vector<std::vector<int>> of_quad(NQ);
   for (int q = 0; q < NQ; ++q) {
-    const int nseg = std::max(1, (len[q] + sc.tau - 1) / sc.tau);
-    for (int g = 0; g < nseg; ++g) {
-      const int seg_lo = lo[q] + g * sc.tau, seg_hi = std::min(lo[q] + len[q], seg_lo + sc.tau);  // bins owned
-      const int base = std::max(0, std::min(seg_lo, row_pitch - sc.tau));                          // bins read
+    int seg_lo = lo[q];
+    const int q_end = lo[q] + len[q];
+    const int pieces = std::max(1, cut_a[q] + cut_b[q]);
+    for (int g = 0; g < pieces; ++g) {
+      const int is_hi = g < cut_a[q] ? 1 : 0;
+      const int tau = 4 * (is_hi ? sc.u_hi : sc.u_lo);
+      const int seg_hi = std::min(q_end, seg_lo + tau);                                 // bins owned
+      const int base = std::max(0, std::min(seg_lo, row_pitch / 4 * 4 - tau));           // bins read
       of_quad[q].push_back((int)pos.size());
-      pos.push_back(Pos{q, seg_lo, seg_hi, base});
+      pos.push_back(Pos{q, seg_lo, seg_hi, base, is_hi});
+      seg_lo = seg_hi;
     }
   }
-  std::vector<int> order(pos.size());
-  std::iota(order.begin(), order.end(), 0);
-  std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return (pos[x].base / 4) % 4 < (pos[y].base / 4) % 4; });
-  const int n_groups = 4 * sc.sets;
-  std::vector<int> filled(n_groups, 0), place_of(pos.size(), 0);
+  std::vector<int> place_of(pos.size(), 0);
   std::vector<char> used(P, 0);
-  for (size_t i = 0; i < order.size(); ++i) {
-    const int grp = (int)(i % n_groups);
-    place_of[order[i]] = 4 * grp + filled[grp]++;
-    used[place_of[order[i]]] = 1;
+  for (int kind = 1; kind >= 0; --kind) {
+    const int first_group = kind ? 0 : 4 * sc.n_hi, n_groups = kind ? 4 * sc.n_hi : 4 * (sc.sets - sc.n_hi);
+    std::vector<int> order;
+    for (size_t i = 0; i < pos.size(); ++i)
+      if (pos[i].is_hi == kind) order.push_back((int)i);
+    if (order.empty() || n_groups == 0) continue;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return (pos[x].base / 4) % 4 < (pos[y].base / 4) % 4; });
+    std::vector<int> filled(n_groups, 0);
+    for (size_t i = 0; i < order.size(); ++i) {
+      const int grp = (int)(i % n_groups);
+      place_of[order[i]] = 4 * (first_group + grp) + filled[grp]++;
+      used[place_of[order[i]]] = 1;
+    }
   }
   int spare = (int)pos.size();  // unused places (all-zero weights) keep slots of their own behind the real ones
   for (int pl = 0; pl < P; ++pl)
@@ -268,11 +345,12 @@ inline MelMfmaSchedule schedule_mel_mfma(const std::vector<float>& melW, int F, 
     sc.base[place] = base;
     sc.slot[place] = (int)p;
     const int set = place / 16, block = place % 16;
-    for (int t = 0; t < sc.tau; ++t) {
+    const int tau = 4 * sc.steps_of(set);
+    for (int t = 0; t < tau; ++t) {
       const int k = base + t;
       if (k < seg_lo || k >= seg_hi || k >= F) continue;
       for (int i = 0; i < 4 && 4 * q + i < M; ++i)
-        sc.a[(((size_t)set * U + t / 4) * 64 + 4 * block + i) * 4 + t % 4] = melW[(size_t)k * M + 4 * q + i];
+        sc.a[(size_t)sc.a_offset(set) + ((size_t)(t / 4) * 64 + 4 * block + i) * 4 + t % 4] = melW[(size_t)k * M + 4 * q + i];
     }
   }
   for (const auto& v : of_quad) sc.max_pos = std::max(sc.max_pos, (int)v.size());
