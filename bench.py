@@ -268,6 +268,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
                     "rehearse the multi-rank control flow on a box with one GPU, together with --one-device)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="N = 1 only: run the all-gather on a one-rank RCCL group (measures what the exchange adds to a step)")
     ap.add_argument("--decode-stream", choices=["side", "same"], default="same",
                     help="side: the detector decode of a step runs on a second HIP stream beside the front-end kernel")
     args = ap.parse_args()
@@ -316,6 +318,12 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(args.backend)
+    elif args.force_collective:
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            os.environ.setdefault("MASTER_PORT", str(sock.getsockname()[1]))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 
     import sed_amd
     from sed_amd import decode as D
@@ -349,7 +357,8 @@ def main():
         # (the gloo rehearsal gathers host copies: gloo's device-tensor path stalls after a few async gathers)
         with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
             out, work = sed_amd.sharding.decode_and_exchange(det, table, 0.6, cap=EVENT_CAP, first_stream=rank * B_PER_GPU,
-                                                             async_op=True, host_staging=(args.backend != "nccl"))
+                                                             async_op=True, host_staging=(args.backend != "nccl"),
+                                                             force_collective=args.force_collective)
         if work is not None:
             pending.append((out, work))
             say(f"step {i}: gather issued, {len(pending)} pending")
@@ -430,6 +439,7 @@ def main():
                                "(BASELINE.json configs[1]) + detector decode of the same streams",
                    "clips_per_gpu": B_PER_GPU, "device_prewarm_s": PREWARM_S, "samples_per_clip": L, "frames_per_clip": T, "pcm": "f32",
                    "parallelism": f"streams sharded over {world} GPU(s), all-gather of event record buffers",
+                   "decode_stream": args.decode_stream, "forced_one_rank_collective": bool(args.force_collective),
                    "step_covers": "fused log-mel kernel + one decode kernel (median, threshold, runs, gap merge, event records) (+ all-gather for N > 1), "
                                   "all on the device; formatting events as host dictionaries is outside the step",
                    "h2d_ms": h2d,
@@ -458,7 +468,7 @@ def main():
                                "single_thread_value": v1, "host_cpus": os.cpu_count(), "cpu_model": model}
     if rank == 0:
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if world > 1 or args.force_collective:
         dist.destroy_process_group()
 
 
