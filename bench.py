@@ -270,8 +270,9 @@ def main():
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--force-collective", action="store_true",
                     help="N = 1 only: run the all-gather on a one-rank RCCL group (measures what the exchange adds to a step)")
-    ap.add_argument("--decode-stream", choices=["side", "same"], default="same",
-                    help="side: the detector decode of a step runs on a second HIP stream beside the front-end kernel")
+    ap.add_argument("--decode-stream", choices=["side", "same"], default="side",
+                    help="side (default): the detector decode and the exchange of a step run on a second HIP stream beside the "
+                         "front-end kernel (their input does not depend on it); same: everything on one stream")
     args = ap.parse_args()
     if args.gpus is None:                      # under a launcher the rank count is the launcher's
         args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
@@ -291,6 +292,16 @@ def main():
         print(json.dumps(res), flush=True)
         return
 
+    # Libraries below (RCCL prints a version banner when a communicator is made) write to stdout: from here on file
+    # descriptor 1 is stderr, and the one JSON line goes to the saved descriptor of the real stdout.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
+    def emit(obj):
+        real_stdout.write(json.dumps(obj) + "\n")
+        real_stdout.flush()
+
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # Not under torchrun: start the ranks as a fresh child process tree (nothing here has touched the GPU yet) and
         # pass its output through; rank 0 of the children prints the JSON line.
@@ -299,7 +310,7 @@ def main():
             port = sock.getsockname()[1]
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-        raise SystemExit(subprocess.run(cmd).returncode)
+        raise SystemExit(subprocess.run(cmd, stdout=real_stdout).returncode)
 
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -467,7 +478,7 @@ def main():
                                          "torchlibrosa formulation (fp32 conv-DFT + mel matmul + 10log10) on torch CPU",
                                "single_thread_value": v1, "host_cpus": os.cpu_count(), "cpu_model": model}
     if rank == 0:
-        print(json.dumps(res), flush=True)
+        emit(res)
     if world > 1 or args.force_collective:
         dist.destroy_process_group()
 
