@@ -40,7 +40,7 @@ sys.path.insert(0, os.path.join(ROOT, "sound-event-detection_amd"))
 SR, CLIP_S, B_PER_GPU = 32000, 10, 256
 EVENT_CAP = 16              # merged events per stream the exchange keeps (a 20-frame trace has at most 10)
 HBM_PEAK_GBS = 8000.0
-PREWARM_S = 0.3
+PREWARM_S = float(os.environ.get("SED_BENCH_PREWARM_S", "0.3"))   # (the environment override is for experiments)
 
 
 def synth_pcm(n_clips, n_samples, device, seed, sr=SR):
@@ -270,9 +270,11 @@ def main():
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--force-collective", action="store_true",
                     help="N = 1 only: run the all-gather on a one-rank RCCL group (measures what the exchange adds to a step)")
-    ap.add_argument("--decode-stream", choices=["side", "same"], default="side",
-                    help="side (default): the detector decode and the exchange of a step run on a second HIP stream beside the "
-                         "front-end kernel (their input does not depend on it); same: everything on one stream")
+    ap.add_argument("--decode-stream", choices=["auto", "side", "same"], default="auto",
+                    help="side: the detector decode and the exchange of a step run on a second HIP stream beside the front-end "
+                         "kernel (their input does not depend on it); same: everything on one stream; auto (default): side when "
+                         "the step holds a collective (N > 1 or --force-collective), where it removes the cross-stream "
+                         "dependency of the all-gather from the front-end's stream, else same")
     args = ap.parse_args()
     if args.gpus is None:                      # under a launcher the rank count is the launcher's
         args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
@@ -356,6 +358,8 @@ def main():
 
     k_events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     pending = []
+    if args.decode_stream == "auto":
+        args.decode_stream = "side" if (world > 1 or args.force_collective) else "same"
     side = torch.cuda.Stream(device=dev) if args.decode_stream == "side" else None
 
     def step(i=None):
@@ -411,6 +415,8 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    if os.environ.get("SED_BENCH_DUMP"):
+        print("kernel ms in launch order:", " ".join(f"{a.elapsed_time(b):.4f}" for a, b in k_events[:64]), file=sys.stderr)
     k_ms = sorted(a.elapsed_time(b) for a, b in k_events)
     kern_ms = sum(k_ms) / max(1, len(k_ms))
 
