@@ -374,17 +374,20 @@ def main():
             out, work = sed_amd.sharding.decode_and_exchange(det, table, 0.6, cap=EVENT_CAP, first_stream=rank * B_PER_GPU,
                                                              async_op=True, host_staging=(args.backend != "nccl"),
                                                              force_collective=args.force_collective)
-        if work is not None:
-            pending.append((out, work))
-            say(f"step {i}: gather issued, {len(pending)} pending")
-            if len(pending) > 4:
-                pending.pop(0)[1].wait()
-                say(f"step {i}: oldest gather done")
+            # (work.wait() makes the CURRENT stream wait for the collective: it is called on the tail's own stream, so the
+            # front-end's stream never carries a dependency on the exchange)
+            if work is not None:
+                pending.append((out, work))
+                say(f"step {i}: gather issued, {len(pending)} pending")
+                if len(pending) > 4:
+                    pending.pop(0)[1].wait()
+                    say(f"step {i}: oldest gather done")
         return y, out
 
     def fence():
-        while pending:
-            pending.pop(0)[1].wait()
+        with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+            while pending:
+                pending.pop(0)[1].wait()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()

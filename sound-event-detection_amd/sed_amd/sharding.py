@@ -14,6 +14,9 @@ import torch
 import torch.distributed as dist
 
 
+FUSED_MAX_FRAMES = 8190   # longest trace whose runs the one-launch decode kernels keep in LDS (sed_threshold_merge_records)
+
+
 def shard_bounds(n_items: int, rank: int, world_size: int) -> Tuple[int, int]:
     """Contiguous block partition: rank r owns [lo, hi); the first n_items % world_size ranks hold one more."""
     if world_size < 1 or not 0 <= rank < world_size or n_items < 0:
@@ -77,11 +80,18 @@ def decode_and_exchange(det_probs: torch.Tensor, time_table: torch.Tensor, gap: 
     """The detector-side tail of one batch on one rank, all on the device and without host synchronisation:
     smoothing + threshold + run extraction + gap merge (src/models/yamnet_train.py:55-71, src/utils/merge_events.py:36-55)
     of this rank's streams and their (stream, class, onset, offset) records in one launch, then the all-gather of the
-    record buffers.  det_probs (S, T, C) fp32 on the device, T <= 8190 (covers the 862-frame CRNN traces of
-    src/models/crnn/crnn.py:181-182 and HTS-AT's 4096-frame maps); returns what all_gather_events returns.
+    record buffers.  det_probs (S, T, C) fp32 on the device; one launch for T <= 8190 (covers the 862-frame CRNN
+    traces of src/models/crnn/crnn.py:181-182 and HTS-AT's 4096-frame maps), three launches with the same records beyond;
+    returns what all_gather_events returns.
     host_staging copies the records to the host before the collective (for backends without a device path)."""
     from . import decode as D
-    records = D.threshold_merge_records(det_probs, threshold, time_table, gap, smoothing, cap, first_stream)
+    if det_probs.dim() == 3 and det_probs.shape[1] > FUSED_MAX_FRAMES:
+        # traces too long for the LDS buffers of the one-launch kernel: the same records from three launches
+        runs, counts = D.threshold_runs(det_probs.contiguous(), threshold, smoothing)
+        runs, counts = D.merge_runs(runs, counts, time_table, gap)
+        records = pack_events(runs, counts, cap, first_stream)
+    else:
+        records = D.threshold_merge_records(det_probs, threshold, time_table, gap, smoothing, cap, first_stream)
     if host_staging and dist.is_initialized() and dist.get_world_size(group) > 1:
         records = records.cpu()          # rehearsals on a backend without a device path (gloo)
     return all_gather_events(records, group=group, async_op=async_op, force_collective=force_collective)

@@ -167,6 +167,24 @@ def test_decode_and_exchange_crnn_traces_against_the_oracle_chain():
     assert n_events > 3 * S
 
 
+def test_decode_and_exchange_beyond_the_one_launch_limit():
+    """Traces longer than the LDS buffers of the one-launch kernel go through threshold_runs + merge_runs + pack_events inside
+    decode_and_exchange; at the limit both paths exist and give the same records."""
+    import sed_amd
+    from sed_amd import decode as D
+    dev = _dev()
+    rng = np.random.default_rng(8)
+    for T in (8190, 8191, 20000):
+        probs = torch.from_numpy(rng.random((3, T, 2), dtype=np.float32)).to(dev)
+        probs[1] = 0.0
+        table = torch.arange(T + 2, dtype=torch.float64, device=dev) * 0.01
+        got = sed_amd.sharding.decode_and_exchange(probs, table, 0.015, cap=T // 2 + 1, first_stream=5, smoothing="median3")
+        runs, counts = D.merge_runs(*D.threshold_runs(probs, 0.5, "median3"), table, 0.015)
+        want = sed_amd.sharding.pack_events(runs, counts, T // 2 + 1, 5)
+        assert got.shape == (3, T // 2 + 2, 4) and torch.equal(got, want), T
+        assert int(got[0, 0, 0]) > 100 and int(got[1, 0, 0]) == 0
+
+
 def test_exchange_over_rccl_one_rank_group(rccl_group):
     """The function bench.py times (decode -> records -> all-gather), with the collective forced on a one-rank RCCL group."""
     import sed_amd

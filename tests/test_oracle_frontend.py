@@ -129,3 +129,24 @@ def test_oracle_reproduces_committed_frontend_vectors():
         want = gold[f"{name}_gold"].astype(np.float64)
         assert got.shape == want.shape, name
         assert np.max(np.abs(got - want)) <= 1e-5 + 1e-6 * np.max(np.abs(want)), name     # float32 storage of dB / neper values
+
+
+def test_cpu_baselines_of_the_bench_compute_the_oracles_values():
+    """The CPU formulations bench.py times (oracle/cpu_baseline.py) are the oracle's features / events, not something cheaper:
+    the TensorFlow-style YAMNet features against yamnet_logmel, and the reference-style decode chain against the oracle chain."""
+    import torch
+    from oracle import cpu_baseline as cb
+    from oracle import decode as od
+    x = of.synth_batch(2, 48000, 16000)
+    got = cb.YamnetCpuFrontend()(torch.from_numpy(x)).numpy()
+    want = of.yamnet_logmel(x, mode="gold")
+    want = want[0] if isinstance(want, tuple) else want
+    assert got.shape == np.asarray(want).shape and np.abs(got - np.asarray(want)).max() < 2e-4
+    rng = np.random.default_rng(3)
+    from scipy.ndimage import gaussian_filter1d
+    probs = (1.0 / (1.0 + np.exp(-8.0 * gaussian_filter1d(rng.standard_normal((6, 300, 3)), 5.0, axis=1)))).astype(np.float32)
+    files, labels, gaps = [f"f{i}" for i in range(6)], {0: "a", 1: "b", 2: "c"}, (0.3, 1.0)
+    raw = od.decode_predictions(od.smooth_and_threshold(probs), files, labels, 43.0)
+    merged = [{k: od.merge_close_events(v, g) for k, v in raw.items()} for g in gaps]
+    ms, n, el, same = cb.time_crnn_chain_cpu(probs, files, labels, 43.0, gaps, raw, merged, budget_s=0.05)
+    assert same is True and n >= 1 and ms > 0
