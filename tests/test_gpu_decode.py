@@ -110,6 +110,40 @@ def test_full_crnn_chain_on_synthetic_probabilities(kat):
     assert sed_amd.decode_probabilities(silent, files[:3], idx_to_label, fps, 0.5) == {f: [] for f in files[:3]}
 
 
+def test_full_size_decode_properties():
+    """Properties that hold whatever the size, on 500 x 862 x 5 probabilities: merging is idempotent, a wider gap never
+    yields more events, merged events cover the raw ones, and the device records agree with the dictionary chain."""
+    import sed_amd
+    rng = np.random.default_rng(99)
+    S, T, C, fps = 500, 862, 5, 44100 / 1024
+    z = rng.standard_normal((S * C, T + 60)).astype(np.float32)
+    z = np.stack([np.convolve(r, np.ones(61, np.float32) / 8.0, mode="valid") for r in z])
+    probs = np.ascontiguousarray((1.0 / (1.0 + np.exp(-2.0 * z))).astype(np.float32).reshape(S, C, T).transpose(0, 2, 1))
+    files = [f"c{i}.wav" for i in range(S)]
+    labels = {0: "car_horn", 1: "cough", 2: "dog_bark", 3: "siren", 4: "gun_shot"}
+    raw = sed_amd.decode_probabilities(probs, files, labels, fps, 0.5)
+    gaps = [0.0, 0.3, 0.6, 1.0, 5.0]
+    merged = sed_amd.merge_close_events_batch(raw, gaps)
+    counts = [sum(len(v) for v in m.values()) for m in merged]
+    assert counts[0] <= sum(len(v) for v in raw.values()) and all(a >= b for a, b in zip(counts, counts[1:])) and counts[-1] >= 1
+    for g, m in zip(gaps, merged):
+        assert sed_amd.merge_close_events_batch(m, g) == m                      # idempotent
+        for f in files[::37]:
+            for ev in raw[f]:                                                    # every raw event lies inside a merged one
+                assert any(k["event_label"] == ev["event_label"] and k["event_onset"] <= ev["event_onset"]
+                           and ev["event_offset"] <= k["event_offset"] for k in m[f]), (g, f, ev)
+    # the device-only path: records of decode_and_exchange name the same events
+    dev = torch.device("cuda", 0)
+    table_host = [round(np.int64(k) * (1.0 / fps), 3) for k in range(T + 2)]
+    table = torch.tensor(table_host, dtype=torch.float64, device=dev)
+    class_of = {v: k for k, v in labels.items()}
+    rec = sed_amd.sharding.decode_and_exchange(torch.from_numpy(probs).to(dev), table, 0.6, cap=128, smoothing="gauss").cpu().numpy()
+    for i, f in enumerate(files):
+        got = sorted((int(c), table_host[int(a)], table_host[int(b)]) for _, c, a, b in rec[i, 1:1 + rec[i, 0, 0]])
+        want = sorted((class_of[e["event_label"]], e["event_onset"], e["event_offset"]) for e in merged[2][f])
+        assert got == want and rec[i, 0, 1] == 0, f
+
+
 def test_decode_predictions_rounding_at_other_frame_rates(golden_dir):
     """The reference's own outputs at eight frame rates (numpy rounding of np.int64 * float), every frame a boundary."""
     import sed_amd
