@@ -19,6 +19,11 @@ formulation, and the CRNN decode chain on 500 files x 862 frames x 5 classes (co
 region decode and the 0.3 / 0.6 / 1.0 s gap merges INCLUDING the host formatting of the event dictionaries, beside the
 pure-Python formulation of the reference on the host.  The default line is unchanged by them.
 
+`--workload server` times one GPU's share of the two-stage stream server (configs[3]: 4096 concurrent 10 s streams over 8
+GPUs = 512 per GPU): YAMNet features of the 512 streams at 16 kHz, the detector decode and the exchange of its event
+records, the cut of the detected events out of the resident 32 kHz PCM into the classifier batch, and the HTS-AT log-mel
+of that batch.  It takes --gpus N like the headline workload (512 streams per rank, weak scaling).
+
 `--gpus N` without a torchrun environment starts the N ranks itself (python -m torch.distributed.run as a child
 process, before this process touches the GPU) and relays rank 0's line.
 """
@@ -257,13 +262,115 @@ def bench_crnn_chain(args):
     return res
 
 
+def bench_server(args, world, rank, dev, dist):
+    """One GPU's share of BASELINE.json configs[3] (two-stage server, 4096 concurrent 10 s detector streams over 8 GPUs):
+    per step and rank, 512 streams go through the detector front-end (YAMNet features, src/models/yamnet_train.py:46-47),
+    the detector decode + exchange (yamnet_train.py:55-71, src/utils/merge_events.py), the hand-off of the detected events
+    to the classifier (src/utils/cut_audio.py:13-53, on the device) and the classifier front-end (HTS-AT log-mel,
+    external/hts_audio_transformer/model/htsat.py:763-764).  The models between the stages are not part of the path: the
+    detector probabilities are fixed synthetic inputs, and the event list the hand-off cuts is their decode."""
+    import sed_amd
+    from sed_amd import decode as D
+    S, secs, cap_s = 512, 10, 3.0
+    det_fe = sed_amd.LogMelFrontend(sed_amd.FrontendConfig.yamnet(), layout="btm")
+    cls_fe = sed_amd.LogMelFrontend(sed_amd.FrontendConfig.htsat())
+    x16 = synth_pcm(S, 16000 * secs, dev, 500 + rank, sr=16000)
+    x32 = synth_pcm(S, 32000 * secs, dev, 900 + rank, sr=32000)
+    g = torch.Generator(device=dev).manual_seed(7 + rank)
+    det = torch.rand((S, 20, 1), generator=g, device=dev)
+    table = torch.tensor([k * 0.48 for k in range(22)], dtype=torch.float64, device=dev)
+    events = []
+    for s_idx, (on, off) in enumerate(D.detect_onsets_offsets_batch(det[:, :, 0].contiguous(), 0.5, 0.48, True)):
+        events += [(s_idx, float(a), float(min(b, secs))) for a, b in zip(on, off) if b > a]
+    cap = int(cap_s * 32000)
+    collective = world > 1 or args.force_collective
+    side = torch.cuda.Stream(device=dev) if collective and args.decode_stream != "same" else None
+    pending = []
+    stage_ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps)]
+
+    def step(i=None):
+        ev = stage_ev[i] if i is not None else None
+        if ev:
+            ev[0].record()
+        feat = det_fe(x16)
+        if ev:
+            ev[1].record()
+        with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+            out, work = sed_amd.sharding.decode_and_exchange(det, table, 0.6, cap=EVENT_CAP, first_stream=rank * S, async_op=True,
+                                                             host_staging=(args.backend != "nccl"),
+                                                             force_collective=args.force_collective)
+            if work is not None:
+                pending.append((out, work))
+                if len(pending) > 4:
+                    pending.pop(0)[1].wait()
+        if ev:
+            ev[2].record()
+        clips, lengths = sed_amd.cut_events(x32, 32000, events, cap=cap)
+        if ev:
+            ev[3].record()
+        y = cls_fe(clips)
+        if ev:
+            ev[4].record()
+        return feat, y
+
+    def fence():
+        with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+            while pending:
+                pending.pop(0)[1].wait()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < PREWARM_S:
+        step()
+        torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        feat, y = step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    names = ["detector_features_ms", "decode_exchange_ms_on_main_stream", "cut_events_ms", "classifier_features_ms"]
+    stages = {n: sum(e[k].elapsed_time(e[k + 1]) for e in stage_ev) / len(stage_ev) for k, n in enumerate(names)}
+    E = len(events)
+    T16, T32 = det_fe.num_frames(16000 * secs, dev), cls_fe.num_frames(cap, dev)
+    cut_bytes = sum(int(min(b, secs) * 32000) - int(a * 32000) for _, a, b in events) * 4 + E * cap * 4
+    alg = S * (16000 * secs * 4 + T16 * 64 * 4) + S * 20 * 4 + cut_bytes + E * (cap * 4 + T32 * 64 * 4)
+    det_alg = S * (16000 * secs * 4 + T16 * 64 * 4)
+    det_ms = stages["detector_features_ms"]
+    return {"metric": "log-mel audio-hours/sec", "value": world * S * secs / 3600.0 * args.steps / elapsed, "unit": "audio-hours/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "two-stage stream server, one GPU's share of BASELINE.json configs[3]: 512 concurrent 10 s streams per GPU -> "
+                                   "YAMNet features (16 kHz) -> detector decode + event exchange -> events cut out of the resident 32 kHz PCM "
+                                   "(3 s rows) -> HTS-AT log-mel of the cut events; value = hours of stream audio served per second",
+                       "streams_per_gpu": S, "events_per_step": E, "classifier_batch": [E, cap], "stage_ms": stages,
+                       "decode_stream": "side" if side is not None else "same", "forced_one_rank_collective": bool(args.force_collective),
+                       "algorithmic_bytes_per_step": alg,
+                       "parallelism": f"streams sharded over {world} GPU(s), all-gather of event record buffers"},
+            "roofline": {"bound": "hbm", "kernel": "stft_mel_kernel<n_fft=512, magnitude, mel+log> (detector features, the longest launch of the step)",
+                         "achieved": det_alg / (det_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": det_alg / (det_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": det_alg, "kernel_ms": det_ms,
+                         "whole_step_achieved_GBps": alg / (elapsed / args.steps) / 1e9}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=None, help="ranks (default: WORLD_SIZE under a launcher, else 1)")
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default 1000; 20 for --workload crnn_chain)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default 100; 3 for --workload crnn_chain)")
-    ap.add_argument("--workload", choices=["htsat", "yamnet", "crnn_chain"], default="htsat",
-                    help="htsat: BASELINE.json configs[1], the headline line; yamnet: configs[0]; crnn_chain: configs[2]")
+    ap.add_argument("--workload", choices=["htsat", "yamnet", "crnn_chain", "server"], default="htsat",
+                    help="htsat: BASELINE.json configs[1], the headline line; yamnet: configs[0]; crnn_chain: configs[2]; "
+                         "server: one GPU's share (512 streams) of the two-stage stream server of configs[3], any --gpus")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
                     "rehearse the multi-rank control flow on a box with one GPU, together with --one-device)")
@@ -284,7 +391,7 @@ def main():
         args.steps = 20 if args.workload == "crnn_chain" else 1000
     if args.warmup is None:
         args.warmup = 3 if args.workload == "crnn_chain" else 100
-    if args.workload != "htsat":
+    if args.workload in ("yamnet", "crnn_chain"):
         if args.gpus != 1 or int(os.environ.get("WORLD_SIZE", "1")) != 1:
             raise SystemExit(f"--workload {args.workload} is a single-GPU line: run it with --gpus 1")
         if not torch.cuda.is_available():
@@ -340,6 +447,14 @@ def main():
 
     import sed_amd
     from sed_amd import decode as D
+
+    if args.workload == "server":
+        res = bench_server(args, world, rank, dev, dist)
+        if rank == 0:
+            emit(res)
+        if world > 1 or args.force_collective:
+            dist.destroy_process_group()
+        return
 
     trace = os.environ.get("SED_BENCH_TRACE")
 
