@@ -282,13 +282,15 @@ def bench_server(args, world, rank, dev, dist):
     events = []
     for s_idx, (on, off) in enumerate(D.detect_onsets_offsets_batch(det[:, :, 0].contiguous(), 0.5, 0.48, True)):
         events += [(s_idx, float(a), float(min(b, secs))) for a, b in zip(on, off) if b > a]
+    import numpy as np
+    events = np.asarray(events, dtype=np.float64).reshape(-1, 3)     # (stream, start s, end s) rows, as a server would hold them
     cap = int(cap_s * 32000)
     collective = world > 1 or args.force_collective
     side = torch.cuda.Stream(device=dev) if collective and args.decode_stream != "same" else None
     pending = []
     stage_ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps)]
 
-    def step(i=None):
+    def step(i=None, fused=True):
         ev = stage_ev[i] if i is not None else None
         if ev:
             ev[0].record()
@@ -305,10 +307,15 @@ def bench_server(args, world, rank, dev, dist):
                     pending.pop(0)[1].wait()
         if ev:
             ev[2].record()
-        clips, lengths = sed_amd.cut_events(x32, 32000, events, cap=cap)
-        if ev:
-            ev[3].record()
-        y = cls_fe(clips)
+        if fused:      # the classifier front-end reads the events straight out of the resident recordings
+            if ev:
+                ev[3].record()
+            y, lengths = sed_amd.logmel_of_events(cls_fe, x32, 32000, events, cap)
+        else:          # the two steps it replaces: cut into a zero-padded batch, then the front-end on the batch
+            clips, lengths = sed_amd.cut_events(x32, 32000, events, cap=cap)
+            if ev:
+                ev[3].record()
+            y = cls_fe(clips)
         if ev:
             ev[4].record()
         return feat, y
@@ -322,27 +329,35 @@ def bench_server(args, world, rank, dev, dist):
             dist.barrier()
             torch.cuda.synchronize()
 
+    def timed(fused):
+        for _ in range(args.warmup):
+            step(fused=fused)
+        fence()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            out = step(i, fused)
+        fence()
+        el = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            el = float(tmax.item())
+        return el, out
+
+    names = ["detector_features_ms", "decode_exchange_ms_on_main_stream", "cut_events_ms", "classifier_features_ms"]
     t_pre = time.perf_counter()
     while time.perf_counter() - t_pre < PREWARM_S:
         step()
         torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        feat, y = step(i)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    two_step_elapsed, (_, y2) = timed(False)
+    two_step_stages = {n: sum(e[k].elapsed_time(e[k + 1]) for e in stage_ev) / len(stage_ev) for k, n in enumerate(names)}
+    elapsed, (feat, y) = timed(True)
+    same_bits = bool(torch.equal(y, y2))
     names = ["detector_features_ms", "decode_exchange_ms_on_main_stream", "cut_events_ms", "classifier_features_ms"]
     stages = {n: sum(e[k].elapsed_time(e[k + 1]) for e in stage_ev) / len(stage_ev) for k, n in enumerate(names)}
     E = len(events)
     T16, T32 = det_fe.num_frames(16000 * secs, dev), cls_fe.num_frames(cap, dev)
-    cut_bytes = sum(int(min(b, secs) * 32000) - int(a * 32000) for _, a, b in events) * 4 + E * cap * 4
+    cut_bytes = int(sum(min(int(b * 32000) - int(a * 32000), cap) for _, a, b in events.tolist())) * 4 + E * cap * 4
     alg = S * (16000 * secs * 4 + T16 * 64 * 4) + S * 20 * 4 + cut_bytes + E * (cap * 4 + T32 * 64 * 4)
     det_alg = S * (16000 * secs * 4 + T16 * 64 * 4)
     det_ms = stages["detector_features_ms"]
@@ -351,8 +366,12 @@ def bench_server(args, world, rank, dev, dist):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "two-stage stream server, one GPU's share of BASELINE.json configs[3]: 512 concurrent 10 s streams per GPU -> "
                                    "YAMNet features (16 kHz) -> detector decode + event exchange -> events cut out of the resident 32 kHz PCM "
-                                   "(3 s rows) -> HTS-AT log-mel of the cut events; value = hours of stream audio served per second",
+                                   "(3 s rows) -> HTS-AT log-mel of the events; value = hours of stream audio served per second",
                        "streams_per_gpu": S, "events_per_step": E, "classifier_batch": [E, cap], "stage_ms": stages,
+                       "handoff": "fused: the classifier front-end reads the events out of the resident recordings (sed_logmel_forward_segments)",
+                       "two_step_handoff": {"ms_per_step": two_step_elapsed / args.steps * 1e3, "stage_ms": two_step_stages,
+                                            "note": "cut_events into a zero-padded (events, 96000) batch, then the front-end on the batch",
+                                            "same_log_mel_bits_as_fused": same_bits},
                        "decode_stream": "side" if side is not None else "same", "forced_one_rank_collective": bool(args.force_collective),
                        "algorithmic_bytes_per_step": alg,
                        "parallelism": f"streams sharded over {world} GPU(s), all-gather of event record buffers"},

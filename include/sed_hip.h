@@ -140,6 +140,18 @@ int sed_plan_set_affine(sed_plan* plan, const float* scale_host, const float* sh
 int sed_logmel_forward(const sed_plan* plan, const void* pcm, int64_t B, int64_t L, int64_t pcm_stride,
                        float* out, int64_t out_stride_b, void* stream);
 
+/* The fused log-mel of SEGMENTS of a resident PCM buffer: the detector -> classifier hand-off of
+ * src/utils/cut_audio.py:13-53 + main.py:123-127 (events cut out of the recordings and written as files for stage 2)
+ * followed by the classifier's front-end (external/hts_audio_transformer/model/htsat.py:763-764), without the copy in
+ * between.  Clip e is the seg_len[e] samples from element seg_off[e] of pcm on (any sample alignment; for a batch
+ * [streams][stride]: stream * stride + first sample) followed by zeros up to L samples, i.e. exactly row e of the
+ * zero-padded batch sed_cut_events would write with cap = L, and the result equals sed_logmel_forward on that batch bit for
+ * bit.  seg_off int64 [n_segments] and seg_len int32 [n_segments] are DEVICE arrays; 0 <= seg_len[e] <= L, and every
+ * segment must lie inside the buffer (not checked: the arrays are not read on the host).  out fp32 [n_segments][T][n_mels],
+ * T = sed_plan_num_frames(plan, L).  Plans with a YAMNet tail or per-frame conditioning return SED_ERR_BAD_ARG. */
+int sed_logmel_forward_segments(const sed_plan* plan, const void* pcm, const int64_t* seg_off, const int32_t* seg_len,
+                                int64_t n_segments, int64_t L, float* out, int64_t out_stride_b, void* stream);
+
 /* Unfused parity path: |STFT|^2 (or |STFT|), replaces spectrogram_extractor(x) at htsat.py:763.
  * out: fp32 [B][T][n_fft/2+1], clip b at out + b*out_stride_b. */
 int sed_spectrogram_forward(const sed_plan* plan, const void* pcm, int64_t B, int64_t L, int64_t pcm_stride,

@@ -74,6 +74,9 @@ struct FrontParams {
   int32_t image_floats, off_queue, off_wave;
   ImageLayout im;
   int32_t mel_sets, mel_u, mel_ulo, mel_nhi, mel_maxpos, n_quads, out_vec, aff_stride;
+  // segment mode (SEG kernels): clip b is seg_len[b] samples starting at element seg_off[b] of pcm, followed by zeros up to L
+  const int64_t* seg_off;
+  const int32_t* seg_len;
   unsigned long long* stamps;  // SED_TIMELINE builds only
 };
 
@@ -123,28 +126,42 @@ __device__ __forceinline__ float pcm16_to_f32(float x, float div, float rcp) {
   return __builtin_fmaf(__builtin_fmaf(-q, div, x), rcp, q);
 }
 
-// Sample `s` of the virtual padded clip: reflect (index -j -> j, L-1+j -> L-1-j) or zeros outside [0, L).
+// Staging copy of a span that touches a clip edge (reflect / zero padding), runs past the stored samples of a segment, or
+// belongs to an int16 plan whose divisor needs the IEEE division: every sample is mapped to its source index on its own.
+// Kept out of line so that its address arithmetic stays out of the streaming loop, but batched like the interior path: a
+// lane forms the source indices of 8 x 4 samples, issues all 32 loads with clamped (never predicated) addresses, and only
+// then selects and stores, so the memory latency is paid once per batch and not once per sample.
 template <typename T>
-__device__ __forceinline__ float load_padded(const T* src, int64_t s, int64_t L, int pad_mode, float div) {
-  if (s < 0) s = (pad_mode == SED_PAD_REFLECT) ? -s : -1;
-  else if (s >= L) s = (pad_mode == SED_PAD_REFLECT) ? 2 * (L - 1) - s : -1;
-  if (s < 0 || s >= L) return 0.0f;
-  if constexpr (std::is_same<T, float>::value) return src[s];
-  else return (float)src[s] / div;
-}
-
-// Cold path of the staging copy: clip edges (reflect / zero padding), unaligned rows.  Kept out of line so that
-// its address arithmetic is not hoisted into the streaming loop.
-__device__ __attribute__((noinline)) void stage_span_edges(const void* pcm, int pcm_kind, float div, int64_t L,
-                                                           int pad_mode, int64_t clip_off, float* dst, int64_t s0,
-                                                           int count, int lane, int hop, int skew) {
-  // sample i of the span goes to float i + skew * (i / hop) (skew 0: the plain layout)
-  if (pcm_kind == SED_PCM_F32) {
-    const float* src = (const float*)pcm + clip_off;
-    for (int i = lane; i < count; i += 64) dst[i + (skew ? skew * (i / hop) : 0)] = load_padded<float>(src, s0 + i, L, pad_mode, 1.0f);
-  } else {
-    const int16_t* src = (const int16_t*)pcm + clip_off;
-    for (int i = lane; i < count; i += 64) dst[i + (skew ? skew * (i / hop) : 0)] = load_padded<int16_t>(src, s0 + i, L, pad_mode, div);
+__device__ __attribute__((noinline)) void stage_span_edges(const T* src, float div, int64_t L, int64_t valid, int pad_mode,
+                                                           float* dst, int64_t s0, int count, int lane, int hop, int skew) {
+  // sample i of the span goes to float i + skew * (i / hop) (skew 0: the plain layout); groups of 4 never straddle a hop
+  if (valid <= 0) {  // a clip without stored samples: zeros, and no load at all
+    for (int i = 4 * lane; i < count; i += 256) st4(dst + i + (skew ? skew * (i / hop) : 0), v4{0.0f, 0.0f, 0.0f, 0.0f});
+    return;
+  }
+  for (int base = 0; base < count; base += 8 * 256) {
+    float v[8][4];
+    static_for<0, 8>([&](auto Kf) {
+      constexpr int k = decltype(Kf)::value;
+      const int i = min(base + 256 * k + 4 * lane, count - 4);
+      static_for<0, 4>([&](auto Ef) {
+        constexpr int e = decltype(Ef)::value;
+        int64_t sidx = s0 + i + e;
+        if (sidx < 0) sidx = (pad_mode == SED_PAD_REFLECT) ? -sidx : -1;
+        else if (sidx >= L) sidx = (pad_mode == SED_PAD_REFLECT) ? 2 * (L - 1) - sidx : -1;
+        const bool ok = sidx >= 0 && sidx < valid;
+        const T raw = src[ok ? sidx : 0];
+        float x;
+        if constexpr (std::is_same<T, float>::value) x = raw;
+        else x = (float)raw / div;
+        v[k][e] = ok ? x : 0.0f;
+      });
+    });
+    static_for<0, 8>([&](auto Kf) {
+      constexpr int k = decltype(Kf)::value;
+      const int i = min(base + 256 * k + 4 * lane, count - 4);
+      st4(dst + i + (skew ? skew * (i / hop) : 0), v4{v[k][0], v[k][1], v[k][2], v[k][3]});
+    });
   }
 }
 
@@ -156,17 +173,21 @@ struct __attribute__((packed, aligned(2))) i16x4_u { short x, y, z, w; };
 // The fast path issues its loads in batches of 8 x 4 samples per lane before the first LDS store, with clamped
 // (never predicated) addresses: a load under a divergent branch would be waited for on its own.
 // HOP / SKEW: the skewed layout (groups of 4 samples never straddle a hop: both are multiples of 4).
+// The clip starts at element clip_off of the PCM buffer and holds `valid` stored samples (then zeros up to p.L).
 template <bool I16, int HOP = 0, int SKEW = 0>
-__device__ __forceinline__ void stage_span(const FrontParams& p, float* dst, int64_t b, int64_t s0, int count, int lane) {
+__device__ __forceinline__ void stage_span(const FrontParams& p, float* dst, int64_t clip_off, int64_t valid, int64_t s0, int count,
+                                           int lane) {
   auto at = [](int i) { if constexpr (SKEW > 0) return i + SKEW * (i / HOP); else return i; };
   // (int16 plans whose divisor failed the three-instruction check take the out-of-line path with the IEEE division)
-  bool fast = s0 >= 0 && s0 + count <= p.L;
+  bool fast = s0 >= 0 && s0 + count <= valid;
   if constexpr (I16) fast = fast && (p.pcm_kind & kPcmDiv3);
   if (!fast) {
-    stage_span_edges(p.pcm, p.pcm_kind & ~kPcmDiv3, p.pcm_div, p.L, p.pad_mode, b * p.pcm_stride, dst, s0, count, lane,
-                     SKEW > 0 ? HOP : 1, SKEW);
+    if constexpr (I16) stage_span_edges<int16_t>((const int16_t*)p.pcm + clip_off, p.pcm_div, p.L, valid, p.pad_mode, dst, s0, count,
+                                                 lane, SKEW > 0 ? HOP : 1, SKEW);
+    else stage_span_edges<float>((const float*)p.pcm + clip_off, 1.0f, p.L, valid, p.pad_mode, dst, s0, count, lane,
+                                 SKEW > 0 ? HOP : 1, SKEW);
   } else if constexpr (!I16) {
-    const float* src = (const float*)p.pcm + b * p.pcm_stride + s0;
+    const float* src = (const float*)p.pcm + clip_off + s0;
     for (int base = 0; base < count; base += 8 * 256) {
       f32x4_u v[8];
       static_for<0, 8>([&](auto Kf) {
@@ -178,7 +199,7 @@ __device__ __forceinline__ void stage_span(const FrontParams& p, float* dst, int
       });
     }
   } else {
-    const int16_t* src = (const int16_t*)p.pcm + b * p.pcm_stride + s0;
+    const int16_t* src = (const int16_t*)p.pcm + clip_off + s0;
     const float rcp = 1.0f / p.pcm_div;  // correctly rounded, as the host's check assumed
     for (int base = 0; base < count; base += 8 * 256) {
       i16x4_u v[8];
@@ -200,8 +221,8 @@ __device__ __forceinline__ void stage_span(const FrontParams& p, float* dst, int
 // that span_blocks * 256 samples from s0 on lie inside the clip, so the last block simply lands past the span.
 // One per-lane address serves four instructions (the 13-bit instruction offset moves the source and the LDS
 // destination together).  Completion: vmcnt.
-__device__ __forceinline__ void stage_span_dma(const FrontParams& p, float* dst, int64_t b, int64_t s0, int lane) {
-  const float* src = (const float*)p.pcm + b * p.pcm_stride + s0 + 4 * lane;
+__device__ __forceinline__ void stage_span_dma(const FrontParams& p, float* dst, int64_t clip_off, int64_t s0, int lane) {
+  const float* src = (const float*)p.pcm + clip_off + s0 + 4 * lane;
   // a rolled loop over groups of four blocks keeps the scalar state to a pointer pair and a counter
   int left = p.span_blocks;
 #pragma nounroll
@@ -226,7 +247,7 @@ __device__ __forceinline__ void stage_span_dma(const FrontParams& p, float* dst,
 // h * (HOP + SKEW), as 16-byte pieces of 256 samples and 4-byte pieces of 64.  The instruction offset moves source and
 // destination together and the LDS base (M0) takes the rest, so two per-lane addresses serve up to four hops.
 template <class G, int HOP, int SKEW>
-__device__ __forceinline__ void stage_span_dma_skewed(const FrontParams& p, float* dst, int64_t b, int64_t s0, int lane) {
+__device__ __forceinline__ void stage_span_dma_skewed(const FrontParams& p, float* dst, int64_t clip_off, int64_t s0, int lane) {
   constexpr int SPAN = (G::FPW - 1) * HOP + G::NFFT;
 #ifdef SED_SPAN_HOPS  // timing experiments: fetch only the first hops of the span (results are then garbage)
   constexpr int HOPS = SED_SPAN_HOPS;
@@ -234,7 +255,7 @@ __device__ __forceinline__ void stage_span_dma_skewed(const FrontParams& p, floa
   constexpr int HOPS = (SPAN + HOP - 1) / HOP;
 #endif
   static_assert(HOP % 64 == 0 && SPAN % 64 == 0 && HOP * 4 * 3 + 4096 > 0, "whole 64-sample pieces");
-  const float* src = (const float*)p.pcm + b * p.pcm_stride + s0;
+  const float* src = (const float*)p.pcm + clip_off + s0;
   static_for<0, (HOPS + 2) / 3>([&](auto Tf) {
     constexpr int h0 = 3 * decltype(Tf)::value;  // three hops per pair of per-lane addresses: offsets stay below 4096 bytes
     const float* s16 = src + h0 * HOP + 4 * lane;
@@ -534,7 +555,10 @@ constexpr int wg_waves_of() { return SPEC_OUT && G::WAVES > 8 ? 8 : G::WAVES; }
 // apart (measured: the first after 58 % of the kernel time) and the last ones run on a nearly empty CU; with the
 // queue they all stay busy until the range is drained.  The span of the next group is ordered as soon as the current
 // one's power rows are consumed, whichever clip it belongs to.
-template <class G, bool MAG, bool SPEC_OUT, bool PRE, bool I16, class Mel>
+// SEG: the clips are segments of a resident PCM buffer (the detector -> classifier hand-off without a copy): clip b holds
+// seg_len[b] samples from element seg_off[b] on and zeros behind them, exactly the row a cut of the segment into a
+// zero-padded batch would hold.
+template <class G, bool MAG, bool SPEC_OUT, bool PRE, bool I16, class Mel, bool SEG = false>
 __global__ void __launch_bounds__((wg_waves_of<G, SPEC_OUT>()) * 64)
 __attribute__((amdgpu_waves_per_eu(SED_WPE((wg_waves_of<G, SPEC_OUT>()) / 4), SED_WPE((wg_waves_of<G, SPEC_OUT>()) / 4))))
 stft_mel_kernel(const FrontParams p) {
@@ -568,14 +592,23 @@ stft_mel_kernel(const FrontParams p) {
   if (tid == 0) *qhead = wg_waves;  // wavefront w starts with group w of the range
   __syncthreads();
 
-  const int g_begin = (int)((int64_t)p.total_groups * blockIdx.x / gridDim.x);
-  const int g_end = (int)((int64_t)p.total_groups * (blockIdx.x + 1) / gridDim.x);
+  // Groups of a workgroup.  Clips of equal length: a contiguous range (a CU streams through contiguous PCM).  Segments:
+  // their work differs (groups behind a short segment are skipped), so chunks of kSegChunk groups are dealt out to the
+  // workgroups round robin: local group v is group (blockIdx + (v / kSegChunk) * gridDim) * kSegChunk + v % kSegChunk,
+  // ascending in v, so the first one past the end ends the workgroup's work.
+  constexpr int kSegChunk = 4;
+  const int g_begin = SEG ? 0 : (int)((int64_t)p.total_groups * blockIdx.x / gridDim.x);
+  const int g_end = SEG ? p.total_groups : (int)((int64_t)p.total_groups * (blockIdx.x + 1) / gridDim.x);
+  auto group_of = [&](int v) {
+    if constexpr (SEG) return (int)((blockIdx.x + (unsigned)(v / kSegChunk) * gridDim.x) * kSegChunk + v % kSegChunk);
+    else return g_begin + v;
+  };
 #ifdef SED_TIMELINE
   const unsigned long long tl_loop = __builtin_amdgcn_s_memrealtime();
   int tl_iters = 0;
 #endif
   constexpr int kGroups = G::FPW / 4;
-  int gi = g_begin + wave;
+  int gi = group_of(wave);
   if (gi < g_end) {
     int b = gi / p.groups_per_clip;
     int f0 = (gi - b * p.groups_per_clip) * G::FPW;
@@ -586,6 +619,15 @@ stft_mel_kernel(const FrontParams p) {
     v4 hval[kGroups][2];
     float* hdst = nullptr;
     int hvalid = 0;
+    // Segments: the log-mel values of a frame made of zeros only (the padding behind a short segment), through the very
+    // expressions of the gather (sum of zero partial sums, log, affine), so that groups of such frames can skip the transform.
+    v4 zc[2] = {v4{0.0f, 0.0f, 0.0f, 0.0f}, v4{0.0f, 0.0f, 0.0f, 0.0f}};
+    if constexpr (SEG && !SPEC_OUT) {
+      v4 zeros[gather_loads<Mel>()];
+      static_for<0, gather_loads<Mel>()>([&](auto If) { zeros[decltype(If)::value] = v4{0.0f, 0.0f, 0.0f, 0.0f}; });
+      zc[0] = mel_gather_finish<Mel>(p, affL, 0, lane, zeros);
+      if (mel_two_rounds<Mel>(p)) zc[1] = mel_gather_finish<Mel>(p, affL, 1, lane, zeros);
+    }
     SED_STAMP_DECL
     while (true) {
 #ifdef SED_TIMELINE
@@ -595,14 +637,49 @@ stft_mel_kernel(const FrontParams p) {
       SED_P(0);
       int taken = 0;
       if (lane == 0) taken = atomicAdd(qhead, 1);
+#ifdef SED_EST_FAST_EDGES  // timing experiments: clip-edge groups take the interior path (their results are then garbage)
+      const int64_t s0 = min(max((int64_t)f0 * p.hop - p.pad_left, (int64_t)0), p.L - dma_reach);
+#else
       const int64_t s0 = (int64_t)f0 * p.hop - p.pad_left;
+#endif
+      if constexpr (SEG && !SPEC_OUT) {
+        // A group whose whole span lies in the zeros behind the segment (and, at the clip's end, whose reflected samples do
+        // too): nothing to fetch and nothing to transform.  (A span ordered early always lies inside the stored samples.)
+        const int64_t valid = p.seg_len[b];
+        const int64_t last = s0 + p.span - 1;  // last sample of the span in the virtual clip
+        const bool all_zero = !staged && (valid <= 0 || (s0 >= valid && (last < p.L || p.pad_mode != SED_PAD_REFLECT ||
+                                                                         2 * (p.L - 1) - last >= valid)));
+        if (all_zero) {
+          if (held) {
+            static_for<0, kGroups>([&](auto Gf) {
+              constexpr int g = decltype(Gf)::value;
+              mel_store(p, hdst + 4 * g * p.n_mels, hval[g][0], 0, hvalid - 4 * g, lane);
+              if (mel_two_rounds<Mel>(p)) mel_store(p, hdst + 4 * g * p.n_mels, hval[g][1], 1, hvalid - 4 * g, lane);
+            });
+          }
+          static_for<0, kGroups>([&](auto Gf) { hval[decltype(Gf)::value][0] = zc[0]; hval[decltype(Gf)::value][1] = zc[1]; });
+          held = true;
+          hdst = p.out + (int64_t)b * p.out_stride_b + (int64_t)f0 * p.n_mels;
+          hvalid = min(G::FPW, p.T - f0);
+          gi = group_of(__builtin_amdgcn_readfirstlane(taken));
+          if (gi >= g_end) break;
+          b = gi / p.groups_per_clip;
+          f0 = (gi - b * p.groups_per_clip) * G::FPW;
+          continue;
+        }
+      }
       LaneState<G> st;
       if (!staged) {
-        if (!I16 && p.dma && s0 >= 0 && s0 + dma_reach <= p.L) {
-          if constexpr (SKEW > 0) stage_span_dma_skewed<G, Mel::HOP, SKEW>(p, X, b, s0, lane);
-          else if (!SED_SKIP(1)) stage_span_dma(p, X, b, s0, lane);
+        // where the clip starts in the PCM buffer and how many stored samples it has (segments: any sample alignment,
+        // so the LDS-DMA path is taken only by segments that start on a 16-byte boundary)
+        int64_t coff, valid;
+        if constexpr (SEG) { coff = p.seg_off[b]; valid = p.seg_len[b]; }
+        else { coff = (int64_t)b * p.pcm_stride; valid = p.L; }
+        if (!I16 && p.dma && s0 >= 0 && s0 + dma_reach <= valid && (!SEG || (coff & 3) == 0)) {
+          if constexpr (SKEW > 0) stage_span_dma_skewed<G, Mel::HOP, SKEW>(p, X, coff, s0, lane);
+          else if (!SED_SKIP(1)) stage_span_dma(p, X, coff, s0, lane);
         } else {
-          stage_span<I16, Mel::HOP, SKEW>(p, X, b, s0, p.span, lane);
+          stage_span<I16, Mel::HOP, SKEW>(p, X, coff, valid, s0, p.span, lane);
         }
       }
       SED_STAMP(0)
@@ -670,7 +747,7 @@ stft_mel_kernel(const FrontParams p) {
       SED_STAMP(4)
       const int nvalid = min(G::FPW, p.T - f0);
       // the group after this one: the one just taken from the queue
-      gi = g_begin + __builtin_amdgcn_readfirstlane(taken);
+      gi = group_of(__builtin_amdgcn_readfirstlane(taken));
       const bool more = gi < g_end;
       const int nb = gi / p.groups_per_clip;
       const int nf0 = (gi - nb * p.groups_per_clip) * G::FPW;
@@ -711,10 +788,15 @@ stft_mel_kernel(const FrontParams p) {
           SED_STAMP(5)
           SED_P(6);
           const int64_t s1 = (int64_t)nf0 * p.hop - p.pad_left;
-          if (!I16 && p.early && more && s1 >= 0 && s1 + dma_reach <= p.L && !SED_SKIP(1)) {
-            if constexpr (SKEW > 0) stage_span_dma_skewed<G, Mel::HOP, SKEW>(p, X, nb, s1, lane);
-            else stage_span_dma(p, X, nb, s1, lane);
-            staged = true;
+          if (!I16 && p.early && more && s1 >= 0 && !SED_SKIP(1)) {
+            int64_t ncoff, nvalid;
+            if constexpr (SEG) { ncoff = p.seg_off[nb]; nvalid = p.seg_len[nb]; }
+            else { ncoff = (int64_t)nb * p.pcm_stride; nvalid = p.L; }
+            if (s1 + dma_reach <= nvalid && (!SEG || (ncoff & 3) == 0)) {
+              if constexpr (SKEW > 0) stage_span_dma_skewed<G, Mel::HOP, SKEW>(p, X, ncoff, s1, lane);
+              else stage_span_dma(p, X, ncoff, s1, lane);
+              staged = true;
+            }
           }
           if (!SED_SKIP(64)) {
             v4 x[2][Mel::ROUNDS][gather_loads<Mel>()];
@@ -743,10 +825,15 @@ stft_mel_kernel(const FrontParams p) {
           if constexpr (g == kGroups - 1) {
             // the power rows are consumed: the next group's span may land on them while the gather runs
             const int64_t s1 = (int64_t)nf0 * p.hop - p.pad_left;
-            if (!I16 && p.early && more && s1 >= 0 && s1 + dma_reach <= p.L && !SED_SKIP(1)) {
-              if constexpr (SKEW > 0) stage_span_dma_skewed<G, Mel::HOP, SKEW>(p, X, nb, s1, lane);
-              else stage_span_dma(p, X, nb, s1, lane);
-              staged = true;
+            if (!I16 && p.early && more && s1 >= 0 && !SED_SKIP(1)) {
+              int64_t ncoff, nvalid;
+              if constexpr (SEG) { ncoff = p.seg_off[nb]; nvalid = p.seg_len[nb]; }
+              else { ncoff = (int64_t)nb * p.pcm_stride; nvalid = p.L; }
+              if (s1 + dma_reach <= nvalid && (!SEG || (ncoff & 3) == 0)) {
+                if constexpr (SKEW > 0) stage_span_dma_skewed<G, Mel::HOP, SKEW>(p, X, ncoff, s1, lane);
+                else stage_span_dma(p, X, ncoff, s1, lane);
+                staged = true;
+              }
             }
           }
           if (!SED_SKIP(64)) {
@@ -1295,11 +1382,16 @@ static int launch_front_shape(const sed_plan* pl, FrontParams p, int64_t B, hipS
   const size_t lds_bytes = (size_t)(p.off_wave + waves * p.wave_floats) * sizeof(float);
   if (lds_bytes > 160 * 1024) return SED_ERR_BAD_ARG;
 #ifdef SED_ONLY_BENCH  // diagnostic builds: one instantiation only, seconds to compile
-  if ((p.pcm_kind & ~kPcmDiv3) == SED_PCM_I16) return SED_ERR_BAD_ARG;
+  if ((p.pcm_kind & ~kPcmDiv3) == SED_PCM_I16 || p.seg_off) return SED_ERR_BAD_ARG;
   auto kern = stft_mel_kernel<G, MAG, SPEC_OUT, PRE, false, Mel>;
 #else
   auto kern = (p.pcm_kind & ~kPcmDiv3) == SED_PCM_I16 ? stft_mel_kernel<G, MAG, SPEC_OUT, PRE, true, Mel>
                                                        : stft_mel_kernel<G, MAG, SPEC_OUT, PRE, false, Mel>;
+  if (p.seg_off) {  // clips are segments of a resident buffer: built for the fused log-mel kernels without per-frame conditioning
+    if constexpr (SPEC_OUT || PRE) return SED_ERR_BAD_ARG;
+    else kern = (p.pcm_kind & ~kPcmDiv3) == SED_PCM_I16 ? stft_mel_kernel<G, MAG, false, false, true, Mel, true>
+                                                         : stft_mel_kernel<G, MAG, false, false, false, Mel, true>;
+  }
 #endif
   // the dynamic LDS limit is a property of the kernel function, set once per instantiation (per device: the attribute
   // lives in the device's code object) to the hardware maximum, so that concurrent launches with different sizes
@@ -1422,12 +1514,12 @@ static int launch_front(const sed_plan* pl, const FrontParams& p, int64_t B, hip
 
 template <bool SPEC_OUT>
 static int front_forward(const sed_plan* pl, const void* pcm, int64_t B, int64_t L, int64_t pcm_stride, float* out,
-                         int64_t out_stride_b, void* stream) {
+                         int64_t out_stride_b, void* stream, const int64_t* seg_off = nullptr, const int32_t* seg_len = nullptr) {
   if (!pl || B < 0 || L < 0) return SED_ERR_BAD_ARG;
   const int64_t T = sed_plan_num_frames(pl, L);
   if (T < 0) return (int)T;
   if (B == 0 || T == 0) return SED_OK;
-  if (!pcm || !out || pcm_stride < L) return SED_ERR_BAD_ARG;
+  if (!pcm || !out || (!seg_off && pcm_stride < L) || ((seg_off == nullptr) != (seg_len == nullptr))) return SED_ERR_BAD_ARG;
   const int64_t row = SPEC_OUT ? pl->cfg.n_fft / 2 + 1 : pl->cfg.n_mels;
   if (out_stride_b < T * row || T > INT32_MAX / 4) return SED_ERR_BAD_ARG;
   int rc = check_device(pl);
@@ -1463,7 +1555,10 @@ static int front_forward(const sed_plan* pl, const void* pcm, int64_t B, int64_t
   p.mel_maxpos = pl->mel_maxpos;
   p.n_quads = pl->n_quads;
   p.aff_stride = pl->im.aff_stride;
-  p.dma = (c.pcm_kind == SED_PCM_F32) && ((uintptr_t)pcm % 16 == 0) && (pcm_stride % 4 == 0) && (c.hop % 4 == 0) ? 1 : 0;  // n_fft/2: a multiple of 4
+  p.seg_off = seg_off;
+  p.seg_len = seg_len;
+  // (segments start anywhere: the kernel takes the LDS-DMA path for those that start on a 16-byte boundary)
+  p.dma = (c.pcm_kind == SED_PCM_F32) && ((uintptr_t)pcm % 16 == 0) && (seg_off || pcm_stride % 4 == 0) && (c.hop % 4 == 0) ? 1 : 0;  // n_fft/2: a multiple of 4
   if (SED_SKIP(2048)) p.dma = 0;  // experiment: register-staged spans for fp32 too
   p.out_vec = (c.n_mels % 4 == 0) && ((uintptr_t)out % 16 == 0) && (out_stride_b % 4 == 0) ? 1 : 0;
   hipStream_t s = (hipStream_t)stream;
@@ -1492,6 +1587,13 @@ static int front_forward(const sed_plan* pl, const void* pcm, int64_t B, int64_t
 extern "C" int sed_logmel_forward(const sed_plan* pl, const void* pcm, int64_t B, int64_t L, int64_t pcm_stride,
                                   float* out, int64_t out_stride_b, void* stream) {
   return front_forward<false>(pl, pcm, B, L, pcm_stride, out, out_stride_b, stream);
+}
+
+extern "C" int sed_logmel_forward_segments(const sed_plan* pl, const void* pcm, const int64_t* seg_off, const int32_t* seg_len,
+                                           int64_t n_segments, int64_t L, float* out, int64_t out_stride_b, void* stream) {
+  if (!seg_off || !seg_len) return SED_ERR_BAD_ARG;
+  if (pl && (pl->cfg.tail_min_samples > 0 || pl->cfg.remove_dc || pl->cfg.preemphasis > 0.0f)) return SED_ERR_BAD_ARG;
+  return front_forward<false>(pl, pcm, n_segments, L, L, out, out_stride_b, stream, seg_off, seg_len);
 }
 
 extern "C" int sed_spectrogram_forward(const sed_plan* pl, const void* pcm, int64_t B, int64_t L, int64_t pcm_stride,

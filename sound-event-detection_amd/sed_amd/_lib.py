@@ -62,6 +62,7 @@ SIGNATURES = {
     "sed_plan_set_window": (C.c_int, [_vp, _vp]),
     "sed_plan_set_affine": (C.c_int, [_vp, _vp, _vp]),
     "sed_logmel_forward": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp]),
+    "sed_logmel_forward_segments": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp]),
     "sed_spectrogram_forward": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp]),
     "sed_mel_from_spectrogram": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "sed_db_normalize": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _vp]),

@@ -460,6 +460,60 @@ class LogMelFrontend(_PlanHolder):
             return out.transpose(1, 2)
         return out
 
+    @torch.no_grad()
+    def forward_segments(self, pcm: torch.Tensor, seg_off, seg_len, n_samples: int):
+        """Log-mel of segments of a resident PCM buffer (the hand-off of handoff.logmel_of_events): clip e is the seg_len[e]
+        samples from ELEMENT seg_off[e] of pcm's storage on, zero-padded to n_samples.  seg_off / seg_len: integer sequences
+        or arrays on the host (checked against the buffer, clamped to n_samples and uploaded in one asynchronous copy), or
+        int64 / int32 tensors already on the device (taken as they are).  Returns (log-mel in the module's layout, lengths (E,)
+        int32 on the device = the sample counts before clamping, for host arrays)."""
+        _require_cuda(pcm, "LogMelFrontend.forward_segments")
+        want = torch.int16 if self.cfg.pcm_kind == L.PCM_I16 else torch.float32
+        if pcm.dtype != want:
+            raise RuntimeError(f"expected dtype {want}, got {pcm.dtype}")
+        if not pcm.is_contiguous() and not (pcm.dim() == 2 and pcm.stride(1) == 1):
+            raise RuntimeError("forward_segments: pcm must be contiguous along the samples")
+        n_samples = int(n_samples)
+        plan = self._plan_for(pcm.device)
+        T = plan.num_frames(n_samples)
+        if torch.is_tensor(seg_off) or torch.is_tensor(seg_len):
+            # arrays already on the device (prepared once for several calls): seg_len must already be clamped to n_samples
+            if not (torch.is_tensor(seg_off) and torch.is_tensor(seg_len) and seg_off.device == pcm.device and
+                    seg_len.device == pcm.device and seg_off.dtype == torch.int64 and seg_len.dtype == torch.int32 and
+                    seg_off.dim() == 1 and seg_off.shape == seg_len.shape and seg_off.is_contiguous() and seg_len.is_contiguous()):
+                raise TypeError("device-side segments: contiguous int64 offsets and int32 lengths of one shape on pcm's device")
+            d_off, d_len, lengths, E = seg_off, seg_len, seg_len, seg_off.shape[0]
+        else:
+            off = np.ascontiguousarray(seg_off, dtype=np.int64).reshape(-1)
+            full = np.ascontiguousarray(seg_len, dtype=np.int64).reshape(-1)
+            if off.shape != full.shape:
+                raise ValueError("seg_off and seg_len must have one entry per segment")
+            E = off.shape[0]
+            # the storage the segments may address: from pcm's first element to the end of its last row
+            extent = (pcm.shape[0] - 1) * pcm.stride(0) + pcm.shape[1] if pcm.dim() == 2 and pcm.shape[0] > 0 else pcm.numel()
+            if E and (off.min() < 0 or full.min() < 0 or (off + full).max() > extent):
+                raise ValueError("a segment lies outside the PCM buffer")
+            # one asynchronous upload from pinned memory: [offsets int64 | clamped lengths int32 | full lengths int32]
+            stage = torch.empty(16 * max(E, 1), dtype=torch.uint8, pin_memory=True)
+            host = stage.numpy()
+            host[:8 * E] = off.view(np.uint8)
+            host[8 * E:12 * E] = np.minimum(full, n_samples).astype(np.int32).view(np.uint8)
+            host[12 * E:16 * E] = np.minimum(full, 2 ** 31 - 1).astype(np.int32).view(np.uint8)
+            d_stage = stage.to(pcm.device, non_blocking=True)
+            d_off, d_len = d_stage[:8 * E].view(torch.int64), d_stage[8 * E:12 * E].view(torch.int32)
+            lengths = d_stage[12 * E:16 * E].view(torch.int32)
+        out = torch.empty((E, T, self.cfg.n_mels), dtype=torch.float32, device=pcm.device)
+        if E and T:
+            with torch.cuda.device(pcm.device):
+                L.check(L.lib.sed_logmel_forward_segments(plan.ptr, pcm.data_ptr(), d_off.data_ptr(), d_len.data_ptr(), E,
+                                                          n_samples, out.data_ptr(), T * self.cfg.n_mels,
+                                                          L.stream_ptr(pcm.device)), "sed_logmel_forward_segments")
+        if self.layout == "b1tm":
+            return out[:, None, :, :], lengths
+        if self.layout == "bmt":
+            return out.transpose(1, 2), lengths
+        return out, lengths
+
 
 class _LogmelPassthrough(nn.Module):
     """Stands where logmel_extractor stood once the fused kernel has taken over its work: forward is the identity,

@@ -48,12 +48,13 @@ def cut_events(pcm: torch.Tensor, sr, events: Sequence[Tuple[int, float, float]]
     lengths = torch.empty((E,), dtype=torch.int32, device=dev)
     if E == 0:
         return clips, lengths
-    # one upload for the three index arrays: [start int64 | end int64 | stream int32]
-    packed = np.empty(20 * E, dtype=np.uint8)
+    # one asynchronous upload from pinned memory for the three index arrays: [start int64 | end int64 | stream int32]
+    stage = torch.empty(20 * E, dtype=torch.uint8, pin_memory=True)
+    packed = stage.numpy()
     packed[:8 * E] = start.view(np.uint8)
     packed[8 * E:16 * E] = end.view(np.uint8)
     packed[16 * E:] = idx.view(np.uint8)
-    d_packed = torch.from_numpy(packed).to(dev)
+    d_packed = stage.to(dev, non_blocking=True)
     d_start, d_end = d_packed[:8 * E].view(torch.int64), d_packed[8 * E:16 * E].view(torch.int64)
     d_idx = d_packed[16 * E:].view(torch.int32)
     with torch.cuda.device(dev):
@@ -62,6 +63,48 @@ def cut_events(pcm: torch.Tensor, sr, events: Sequence[Tuple[int, float, float]]
                                      d_end.data_ptr(), E, clips.data_ptr(), cap, lengths.data_ptr(),
                                      L.stream_ptr(dev)), "sed_cut_events")
     return clips, lengths
+
+
+def _event_ranges(events, sr, n):
+    """(stream, first sample, sample count) of every event with the index arithmetic of cut_audio.py:37-38 and numpy slicing:
+    int(sec * sr) truncated toward zero, negative indices counted from the end, both ends clipped to the recording."""
+    E = len(events)
+    ev = np.asarray(events, dtype=np.float64).reshape(E, 3)
+    idx = ev[:, 0].astype(np.int64)
+    start = np.trunc(ev[:, 1] * sr).astype(np.int64)
+    end = np.trunc(ev[:, 2] * sr).astype(np.int64)
+    a = np.clip(np.where(start < 0, start + n, start), 0, n)
+    b = np.clip(np.where(end < 0, end + n, end), 0, n)
+    return idx, a, np.maximum(b - a, 0)
+
+
+def logmel_of_events(frontend, pcm: torch.Tensor, sr, events: Sequence[Tuple[int, float, float]], cap: int):
+    """The classifier front-end on the detected events WITHOUT the cut in between: the fused log-mel kernel reads every
+    event's samples straight out of the resident recordings (src/utils/cut_audio.py:13-53 + main.py:123-127 write the events
+    as files for stage 2; external/hts_audio_transformer/model/htsat.py:763-764 is the front-end they feed).
+
+    pcm (S, L) fp32 or int16 on the device; events (stream index, start_sec, end_sec); cap = samples per classifier clip
+    (longer events are truncated, shorter ones zero-padded, as cut_events(..., cap=cap) does).  frontend: a LogMelFrontend
+    whose configuration takes pcm's sample type (for int16 recordings: pcm_kind=1 and the divisor of the hand-off).
+    Returns (log-mel of the E events in the frontend's layout, lengths (E,) int32 on the device): the same values, bit for
+    bit, as frontend(cut_events(pcm, sr, events, cap)[0]), with neither the (E, cap) batch nor its kernel."""
+    from . import frontend as F
+    if not isinstance(frontend, F.LogMelFrontend):
+        raise TypeError("logmel_of_events needs a sed_amd.LogMelFrontend")
+    if not pcm.is_cuda:
+        raise RuntimeError(f"logmel_of_events: pcm is on {pcm.device}; the hand-off runs only on a ROCm device")
+    if pcm.dim() != 2 or pcm.dtype not in (torch.float32, torch.int16):
+        raise RuntimeError("logmel_of_events: expected a (streams, samples) fp32 or int16 tensor")
+    S, n = pcm.shape
+    if pcm.stride(1) != 1 or (S > 1 and pcm.stride(0) < n):
+        pcm = pcm.contiguous()
+    cap = int(cap)
+    if cap < 1:
+        raise ValueError("cap must be at least one sample")
+    idx, a, length = _event_ranges(events, sr, n)
+    if len(idx) and (idx.min() < 0 or idx.max() >= S):
+        raise ValueError("event names a stream outside the batch")
+    return frontend.forward_segments(pcm, idx * max(pcm.stride(0), n) + a, length, cap)
 
 
 def cut_events_from_audio(pcm: torch.Tensor, sr, filenames: Sequence[str], events_list: Dict[str, List[dict]],

@@ -90,3 +90,50 @@ def test_cut_events_from_audio_names_and_rows():
             assert np.array_equal(row[:len(sl)], sl) and not row[len(sl):].any()
     fe = sed_amd.LogMelFrontend(sed_amd.FrontendConfig.htsat())
     assert fe(clips).shape[0] == 3                                        # the rows feed the classifier front-end as is
+
+
+def test_logmel_of_events_equals_cut_then_front_end():
+    """The fused hand-off (the front-end kernel reads the events straight out of the resident recordings) against the two
+    steps it replaces, cut_events then LogMelFrontend: the same log-mel bit for bit, for fp32 and int16 recordings, events
+    that start on any sample, truncated and empty events, negative (from-the-end) times, strided rows, all three layouts."""
+    import sed_amd
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(31)
+    sr, S, n = 32000, 6, 10 * 32000
+    x = torch.from_numpy((0.2 * rng.standard_normal((S, n + 24))).astype(np.float32)).to(dev)
+    events = [(0, 0.0, 1.0), (0, 0.48, 2.88), (1, 5.279999999999999, 8.16), (2, 9.5, 12.0), (3, 1.00003125, 1.5),
+              (5, 0.0, 10.0), (4, 3.0, 3.0), (4, 4.0, 3.5), (2, -2.0, -0.5), (1, 0.96, 0.96 + 1e-4), (3, 2.5, 2.5 + 1023 / sr),
+              (5, 7.77, 9.99), (0, 9.999, 10.0)]
+    for rows, cap in ((x[:, :n], 96000), (x[:, 3:n + 3], 64000), (x[:, 8:n + 8], 96000), (x[:, :n], 1025)):
+        for layout in ("b1tm", "btm", "bmt"):
+            fe = sed_amd.LogMelFrontend(sed_amd.FrontendConfig.htsat(), layout=layout)
+            clips, lens = sed_amd.cut_events(rows, sr, events, cap=cap)
+            want = fe(clips)
+            got, glens = sed_amd.logmel_of_events(fe, rows, sr, events, cap)
+            assert got.shape == want.shape and torch.equal(got, want), (cap, layout)
+            assert torch.equal(glens, lens)
+    # other flavours of the fused kernel (dynamic mel shape, n_fft 2048 with constant padding, magnitude spectrum)
+    for cfg in (sed_amd.FrontendConfig.htsat(mel_bins=40, fmin=0, fmax=16000), sed_amd.FrontendConfig.crnn(), sed_amd.FrontendConfig.db_mel()):
+        fe = sed_amd.LogMelFrontend(cfg, layout="btm")
+        clips, _ = sed_amd.cut_events(x[:, :n], sr, events, cap=40000)
+        got, _ = sed_amd.logmel_of_events(fe, x[:, :n], sr, events, 40000)
+        assert torch.equal(got, fe(clips))
+    # int16 recordings: the front-end's own int16 path with the divisor of the hand-off
+    xi = torch.from_numpy(rng.integers(-20000, 20000, (S, n + 8), dtype=np.int16)).to(dev)
+    fe16 = sed_amd.LogMelFrontend(sed_amd.FrontendConfig.htsat(pcm_kind=1, pcm_divisor=32768.0), layout="btm")
+    fe32 = sed_amd.LogMelFrontend(sed_amd.FrontendConfig.htsat(), layout="btm")
+    for rows in (xi[:, :n], xi[:, 1:n + 1]):
+        clips, lens = sed_amd.cut_events(rows, sr, events, cap=96000, pcm_divisor=32768.0)
+        got, glens = sed_amd.logmel_of_events(fe16, rows, sr, events, 96000)
+        assert torch.equal(got, fe32(clips)) and torch.equal(glens, lens)
+    # no events, and refusals
+    empty, elens = sed_amd.logmel_of_events(fe32, x[:, :n], sr, [], 96000)
+    assert empty.shape == (0, fe32.num_frames(96000, dev), 64) and elens.numel() == 0
+    with pytest.raises(ValueError):
+        sed_amd.logmel_of_events(fe32, x[:, :n], sr, [(S, 0.0, 1.0)], 96000)
+    with pytest.raises(RuntimeError):
+        sed_amd.logmel_of_events(fe32, x[:, :n].cpu(), sr, events, 96000)
+    with pytest.raises(RuntimeError):
+        sed_amd.logmel_of_events(fe16, x[:, :n], sr, events, 96000)                  # sample type of the plan
+    with pytest.raises(ValueError):
+        sed_amd.logmel_of_events(sed_amd.LogMelFrontend(sed_amd.FrontendConfig.yamnet()), x[:, :n], 16000, events[:2], 48000)
