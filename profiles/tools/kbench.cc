@@ -1,6 +1,6 @@
 // Times sed_logmel_forward of one or more builds of libsedhip.so on the headline workload (or another flavour) and
 // compares their outputs with the first build's.  Diagnostic tool:
-//   hipcc -O2 -o kbench kbench.cc -ldl ;  ./kbench [-c htsat|htsat_i16|yamnet|crnn|dbmel|kaldi|htsat1h] [-n steps] lib1.so [lib2.so ...]
+//   hipcc -O2 -o kbench kbench.cc -ldl ;  ./kbench [-c htsat|htsat_i16|yamnet|crnn|dbmel|kaldi|htsat1h] [-n steps] [-b clips] lib1.so [lib2.so ...]
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
@@ -45,11 +45,13 @@ static Lib open_lib(const char* path) {
 int main(int argc, char** argv) {
   std::string cfgname = "htsat";
   int steps = 200, warm = 30;
+  long long batch = 0;  // 0: the flavour's own batch
   std::vector<const char*> libs;
   for (int i = 1; i < argc; ++i) {
     if (!strcmp(argv[i], "-c") && i + 1 < argc) cfgname = argv[++i];
     else if (!strcmp(argv[i], "-n") && i + 1 < argc) steps = atoi(argv[++i]);
     else if (!strcmp(argv[i], "-w") && i + 1 < argc) warm = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "-b") && i + 1 < argc) batch = atoll(argv[++i]);
     else libs.push_back(argv[i]);
   }
   if (libs.empty()) { fprintf(stderr, "usage: kbench [-c cfg] [-n steps] lib.so ...\n"); return 2; }
@@ -84,6 +86,7 @@ int main(int argc, char** argv) {
     B = 512; L = 160000;
   } else { fprintf(stderr, "unknown cfg %s\n", cfgname.c_str()); return 2; }
 
+  if (batch > 0) B = batch;
   // deterministic noise + a tone + a stretch of silence
   const size_t n = (size_t)B * L;
   const size_t esz = i16 ? 2 : 4;
@@ -147,8 +150,8 @@ int main(int argc, char** argv) {
       }
     }
     const double bytes = (double)n * esz + (double)on * 4;
-    printf("%-44s %s T=%lld  best %8.1f us  mean %8.1f us  %6.2f TB/s (%.1f%% of 8 TB/s)  mean|y| %.6f  nonfinite %zu", libs[li],
-           cfgname.c_str(), (long long)T, best, sum / 3, bytes / best / 1e6, bytes / best / 1e6 / 8 * 100, asum / on, nbad);
+    printf("%-44s %s B=%lld T=%lld  best %8.1f us  mean %8.1f us  %6.2f TB/s (%.1f%% of 8 TB/s)  mean|y| %.6f  nonfinite %zu", libs[li],
+           cfgname.c_str(), (long long)B, (long long)T, best, sum / 3, bytes / best / 1e6, bytes / best / 1e6 / 8 * 100, asum / on, nbad);
     if (!ref.empty()) printf("  max|d vs first| %.3g at %zu", maxd, worst);
     printf("\n");
     fflush(stdout);

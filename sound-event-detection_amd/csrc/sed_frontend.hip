@@ -645,7 +645,7 @@ stft_mel_kernel(const FrontParams p) {
       if constexpr (SEG && !SPEC_OUT) {
         // A group whose whole span lies in the zeros behind the segment (and, at the clip's end, whose reflected samples do
         // too): nothing to fetch and nothing to transform.  (A span ordered early always lies inside the stored samples.)
-        const int64_t valid = p.seg_len[b];
+        const int64_t valid = min((int64_t)p.seg_len[b], p.L);
         const int64_t last = s0 + p.span - 1;  // last sample of the span in the virtual clip
         const bool all_zero = !staged && (valid <= 0 || (s0 >= valid && (last < p.L || p.pad_mode != SED_PAD_REFLECT ||
                                                                          2 * (p.L - 1) - last >= valid)));
@@ -673,7 +673,7 @@ stft_mel_kernel(const FrontParams p) {
         // where the clip starts in the PCM buffer and how many stored samples it has (segments: any sample alignment,
         // so the LDS-DMA path is taken only by segments that start on a 16-byte boundary)
         int64_t coff, valid;
-        if constexpr (SEG) { coff = p.seg_off[b]; valid = p.seg_len[b]; }
+        if constexpr (SEG) { coff = p.seg_off[b]; valid = min((int64_t)p.seg_len[b], p.L); }  // never past the row, whatever the table says
         else { coff = (int64_t)b * p.pcm_stride; valid = p.L; }
         if (!I16 && p.dma && s0 >= 0 && s0 + dma_reach <= valid && (!SEG || (coff & 3) == 0)) {
           if constexpr (SKEW > 0) stage_span_dma_skewed<G, Mel::HOP, SKEW>(p, X, coff, s0, lane);
@@ -790,7 +790,7 @@ stft_mel_kernel(const FrontParams p) {
           const int64_t s1 = (int64_t)nf0 * p.hop - p.pad_left;
           if (!I16 && p.early && more && s1 >= 0 && !SED_SKIP(1)) {
             int64_t ncoff, nvalid;
-            if constexpr (SEG) { ncoff = p.seg_off[nb]; nvalid = p.seg_len[nb]; }
+            if constexpr (SEG) { ncoff = p.seg_off[nb]; nvalid = min((int64_t)p.seg_len[nb], p.L); }
             else { ncoff = (int64_t)nb * p.pcm_stride; nvalid = p.L; }
             if (s1 + dma_reach <= nvalid && (!SEG || (ncoff & 3) == 0)) {
               if constexpr (SKEW > 0) stage_span_dma_skewed<G, Mel::HOP, SKEW>(p, X, ncoff, s1, lane);
@@ -827,7 +827,7 @@ stft_mel_kernel(const FrontParams p) {
             const int64_t s1 = (int64_t)nf0 * p.hop - p.pad_left;
             if (!I16 && p.early && more && s1 >= 0 && !SED_SKIP(1)) {
               int64_t ncoff, nvalid;
-              if constexpr (SEG) { ncoff = p.seg_off[nb]; nvalid = p.seg_len[nb]; }
+              if constexpr (SEG) { ncoff = p.seg_off[nb]; nvalid = min((int64_t)p.seg_len[nb], p.L); }
               else { ncoff = (int64_t)nb * p.pcm_stride; nvalid = p.L; }
               if (s1 + dma_reach <= nvalid && (!SEG || (ncoff & 3) == 0)) {
                 if constexpr (SKEW > 0) stage_span_dma_skewed<G, Mel::HOP, SKEW>(p, X, ncoff, s1, lane);
@@ -1379,6 +1379,17 @@ static int launch_front_shape(const sed_plan* pl, FrontParams p, int64_t B, hipS
   if (debug_waves > 0) waves = std::min(waves, debug_waves);
 #endif
   while (waves > 1 && (size_t)(p.off_wave + waves * p.wave_floats) * sizeof(float) > 160 * 1024) --waves;
+  // groups of FPW frames; one workgroup per CU, each with a contiguous share of the groups
+  p.groups_per_clip = (p.T + G::FPW - 1) / G::FPW;
+  const int64_t total_groups = (int64_t)p.groups_per_clip * B;
+  if (total_groups > INT32_MAX / 2) return SED_ERR_BAD_ARG;
+  p.total_groups = (int32_t)total_groups;
+  // few groups (a handful of streams): rather every CU with a few wavefronts than a few CUs with all of theirs (measured
+  // 11.1 -> 9.4 us for 1 .. 4 streams of 10 s).  A large plan image is copied into LDS by at least two wavefronts.
+  if (total_groups < (int64_t)waves * pl->num_cus) {
+    const int64_t floor_waves = p.image_floats > 8192 ? 2 : 1;
+    waves = (int)std::min<int64_t>(waves, std::max<int64_t>(floor_waves, (total_groups + pl->num_cus - 1) / pl->num_cus));
+  }
   const size_t lds_bytes = (size_t)(p.off_wave + waves * p.wave_floats) * sizeof(float);
   if (lds_bytes > 160 * 1024) return SED_ERR_BAD_ARG;
 #ifdef SED_ONLY_BENCH  // diagnostic builds: one instantiation only, seconds to compile
@@ -1406,11 +1417,6 @@ static int launch_front_shape(const sed_plan* pl, FrontParams p, int64_t B, hipS
       done.push_back(key);
     }
   }
-  // groups of FPW frames; one workgroup per CU, each with a contiguous share of the groups
-  p.groups_per_clip = (p.T + G::FPW - 1) / G::FPW;
-  const int64_t total_groups = (int64_t)p.groups_per_clip * B;
-  if (total_groups > INT32_MAX / 2) return SED_ERR_BAD_ARG;
-  p.total_groups = (int32_t)total_groups;
   const int blocks = (int)std::min<int64_t>((total_groups + waves - 1) / waves, (int64_t)pl->num_cus);
 #ifdef SED_TIMELINE
   static unsigned long long* d_tl = nullptr;
