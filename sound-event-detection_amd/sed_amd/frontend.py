@@ -142,6 +142,14 @@ class _Plan:
         L.check(t, "sed_plan_num_frames")
         return t
 
+    def set_window(self, window_full) -> None:
+        """Replace the plan's window by n_fft fp32 values (already padded to n_fft)."""
+        w = torch.as_tensor(np.asarray(window_full, dtype=np.float32)).contiguous()
+        if w.numel() != self.cfg.n_fft:
+            raise ValueError(f"window must have n_fft = {self.cfg.n_fft} values")
+        with torch.cuda.device(self.device):
+            L.check(L.lib.sed_plan_set_window(self.ptr, w.data_ptr()), "sed_plan_set_window")
+
     def set_mel_weights(self, melW: torch.Tensor) -> None:
         w = melW.detach().to("cpu", torch.float32).contiguous()
         if tuple(w.shape) != (self.cfg.n_bins, self.cfg.n_mels):
@@ -247,21 +255,14 @@ class _STFTTables(nn.Module):
     quarter of the entries differ by one fp32 ulp from the exactly reduced angle cos/sin(2 pi (n k mod N) / N).  The kernels
     do not read these tensors."""
 
-    _cache: dict = {}   # (n_fft, win_length) -> (real, imag) fp32 arrays (F, 1, n_fft), shared by construction and load checks
+    _cache: dict = {}   # (n_fft, win_length, window key) -> (real, imag) fp32 arrays (F, 1, n_fft), shared by construction and load checks
 
     @classmethod
-    def weights(cls, n_fft: int, win_length: int):
-        key = (int(n_fft), int(win_length))
+    def weights(cls, n_fft: int, win_length: int, window="hann"):
+        key = (int(n_fft), int(win_length), _window_key(window))
         hit = cls._cache.get(key)
         if hit is None:
-            # the fp64 window of scipy.signal.get_window('hann', win_length, fftbins=True) (general_cosine: 0.5 + 0.5 cos(fac),
-            # fac = linspace(-pi, pi, win_length + 1) without its last point), centred in n_fft samples like librosa.util.pad_center
-            fac = np.linspace(-np.pi, np.pi, win_length + 1)[:-1]
-            win = np.zeros(win_length)
-            for k, a in enumerate((0.5, 0.5)):
-                win += a * np.cos(k * fac)
-            lpad = (n_fft - win_length) // 2
-            window_full = np.pad(win, (lpad, n_fft - win_length - lpad))
+            window_full = fft_window(window, win_length, n_fft)
             # columns 0 .. n_fft/2 of torchlibrosa's n_fft x n_fft matrix, the only ones it keeps (same elementwise expressions)
             (x, y) = np.meshgrid(np.arange(n_fft // 2 + 1), np.arange(n_fft))
             omega = np.exp(-2 * np.pi * 1j / n_fft)
@@ -270,14 +271,53 @@ class _STFTTables(nn.Module):
                    np.ascontiguousarray(np.imag(W).T.astype(np.float32)[:, None, :]))
             for a in hit:
                 a.setflags(write=False)
-            cls._cache[key] = hit
+            if key[2] is not None:
+                cls._cache[key] = hit
         return hit
 
-    def __init__(self, n_fft: int, win_length: int):
+    def __init__(self, n_fft: int, win_length: int, window="hann"):
         super().__init__()
-        real, imag = self.weights(n_fft, win_length)
+        real, imag = self.weights(n_fft, win_length, window)
         self.conv_real = _ConvWeight(torch.from_numpy(real.copy()))
         self.conv_imag = _ConvWeight(torch.from_numpy(imag.copy()))
+
+
+def _window_key(window):
+    """Hashable name of a window specification, None for arrays and callables (not cached)."""
+    if isinstance(window, str):
+        return window
+    if isinstance(window, (int, float)):
+        return float(window)
+    if isinstance(window, tuple) and all(isinstance(a, (str, int, float)) for a in window):
+        return window
+    return None
+
+
+def fft_window(window, win_length: int, n_fft: int) -> np.ndarray:
+    """The fp64 window torchlibrosa's STFT multiplies into its DFT matrix (stft.py: librosa.filters.get_window(window,
+    win_length, fftbins=True), then librosa.util.pad_center to n_fft): a name / tuple / number goes to
+    scipy.signal.get_window as librosa passes it on, a callable is called with win_length, an array is taken as it is."""
+    win_length, n_fft = int(win_length), int(n_fft)
+    if isinstance(window, str) and window == "hann":
+        # scipy's general_cosine for 'hann' written out: 0.5 + 0.5 cos(fac), fac = linspace(-pi, pi, win_length + 1)
+        # without its last point
+        fac = np.linspace(-np.pi, np.pi, win_length + 1)[:-1]
+        win = np.zeros(win_length)
+        for k, a in enumerate((0.5, 0.5)):
+            win += a * np.cos(k * fac)
+    elif callable(window):
+        win = np.asarray(window(win_length), dtype=np.float64)
+    elif isinstance(window, (str, tuple, int, float)):
+        from scipy.signal import get_window
+        win = np.asarray(get_window(window, win_length, fftbins=True), dtype=np.float64)
+    else:
+        win = np.asarray(window, dtype=np.float64)
+    if win.shape != (win_length,):
+        raise ValueError(f"window must have win_length = {win_length} samples, got shape {win.shape}")
+    if not np.all(np.isfinite(win)):
+        raise ValueError("window must be finite")
+    lpad = (n_fft - win_length) // 2
+    return np.pad(win, (lpad, n_fft - win_length - lpad))
 
 
 class Spectrogram(_PlanHolder):
@@ -292,14 +332,17 @@ class Spectrogram(_PlanHolder):
                  power=2.0, freeze_parameters=True):
         super().__init__()
         assert pad_mode in ["constant", "reflect"]
-        if window != "hann":
-            raise ValueError("only the 'hann' window is built")
         self.n_fft = n_fft
         self.win_length = n_fft if win_length is None else win_length
         self.hop_length = int(self.win_length // 4) if hop_length is None else hop_length
         self.center, self.pad_mode, self.power = center, pad_mode, power
-        self.stft = _STFTTables(n_fft, self.win_length)
+        self.window = window
+        self.stft = _STFTTables(n_fft, self.win_length, window)
         self.register_load_state_dict_post_hook(_check_stft_tables)
+
+    def _sync_plan(self, plan: _Plan) -> None:
+        if not (isinstance(self.window, str) and self.window == "hann"):  # the plan's own window is the periodic Hann
+            plan.set_window(fft_window(self.window, self.win_length, self.n_fft))
 
     def _cfg(self) -> FrontendConfig:
         return FrontendConfig(1, self.n_fft, self.win_length, self.hop_length, bool(self.center),
@@ -319,11 +362,12 @@ class Spectrogram(_PlanHolder):
 
 
 def _check_stft_tables(module, incompatible_keys):
-    ref = dict(zip(("conv_real", "conv_imag"), _STFTTables.weights(module.n_fft, module.win_length)))
+    window = getattr(module, "window", "hann")
+    ref = dict(zip(("conv_real", "conv_imag"), _STFTTables.weights(module.n_fft, module.win_length, window)))
     for name in ("conv_real", "conv_imag"):
         got = getattr(module.stft, name).weight.detach().cpu()
         if got.shape != ref[name].shape or not torch.allclose(got, torch.from_numpy(ref[name].copy()), atol=1e-5, rtol=0):
-            raise RuntimeError(f"loaded stft.{name}.weight is not the Hann-windowed DFT matrix this module computes")
+            raise RuntimeError(f"loaded stft.{name}.weight is not the windowed DFT matrix this module computes")
 
 
 class LogmelFilterBank(_PlanHolder):
@@ -380,11 +424,15 @@ class LogMelFrontend(_PlanHolder):
     """
 
     def __init__(self, cfg: FrontendConfig, layout: str = "b1tm", melW: Optional[torch.Tensor] = None,
-                 mel_owner: Optional[nn.Module] = None, stft: Optional[nn.Module] = None):
+                 mel_owner: Optional[nn.Module] = None, stft: Optional[nn.Module] = None, window="hann"):
         super().__init__()
         if layout not in ("b1tm", "btm", "bmt"):
             raise ValueError(layout)
         self.cfg, self.layout = cfg, layout
+        # any other window than the configuration's own Hann: torchlibrosa's window argument (see fft_window)
+        self.window = window
+        if not (isinstance(window, str) and window == "hann") and cfg.win_align != L.WIN_CENTER:
+            raise ValueError("a window argument goes with the centred (torchlibrosa / librosa) window placement")
         if mel_owner is None:
             self.melW = nn.Parameter(mel_filterbank(cfg) if melW is None else melW.detach().clone().float().cpu(),
                                      requires_grad=False)
@@ -420,7 +468,7 @@ class LogMelFrontend(_PlanHolder):
                              fmin=float(m.fmin), fmax=float(m.fmax), log_kind=L.LOG_DB10, amin=float(m.amin),
                              ref=float(m.ref))
         return cls(cfg, layout, melW=None if mel_owner is not None else m.melW, mel_owner=mel_owner,
-                   stft=s.stft if keep_stft else None)
+                   stft=s.stft if keep_stft else None, window=getattr(s, "window", "hann"))
 
     def set_affine(self, scale: Optional[torch.Tensor], shift: Optional[torch.Tensor]) -> None:
         self.affine_scale = None if scale is None else scale.detach().clone().float()
@@ -442,6 +490,8 @@ class LogMelFrontend(_PlanHolder):
         return (id(mel), mel._version, self._affine_version)
 
     def _sync_plan(self, plan: _Plan) -> None:
+        if not (isinstance(self.window, str) and self.window == "hann"):
+            plan.set_window(fft_window(self.window, self.cfg.win_length, self.cfg.n_fft))
         plan.set_mel_weights(self._mel())
         plan.set_affine(self.affine_scale, self.affine_shift)
 

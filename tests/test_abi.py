@@ -80,6 +80,22 @@ def test_host_tables_match_oracle():
         assert np.array_equal(of.hann_periodic(n), sw)
         ss = get_window("hann", n, fftbins=False)
         assert np.array_equal(sed_amd.hann_window(n_fft, n, 1, 1).numpy()[:n], ss.astype(np.float32)), n
+    # the window argument of the torchlibrosa surface: what scipy returns for the specification, centred in n_fft samples
+    from sed_amd.frontend import _STFTTables, fft_window
+    assert np.array_equal(fft_window("hann", 800, 1024), of.pad_center(get_window("hann", 800, fftbins=True), 1024))
+    for spec in ("hamming", ("kaiser", 8.0), ("tukey", 0.25), "boxcar"):
+        want = of.pad_center(get_window(spec, 400, fftbins=True).astype(np.float64), 512)
+        assert np.array_equal(fft_window(spec, 400, 512), want)
+        real, imag = _STFTTables.weights(512, 400, spec)
+        wr, wi = of.torchlibrosa_conv_weights(512, want)
+        assert np.array_equal(real, wr) and np.array_equal(imag, wi)
+    ham = get_window("hamming", 400, fftbins=True)
+    assert np.array_equal(fft_window(ham, 400, 512), fft_window("hamming", 400, 512))
+    assert np.array_equal(fft_window(lambda n: get_window("hamming", n), 400, 512), fft_window("hamming", 400, 512))
+    with pytest.raises(ValueError):
+        fft_window(ham[:-1], 400, 512)
+    with pytest.raises(ValueError):
+        fft_window(np.full(400, np.nan), 400, 512)
 
 
 def test_modules_construct_and_refuse_cpu_input():

@@ -102,6 +102,53 @@ def test_logmel_top_db_and_power_variants():
     assert np.max(np.abs(nolog.cpu().numpy()[:, 0] - mel) / mel.max()) < 1e-5
 
 
+def test_other_windows_of_the_torchlibrosa_surface():
+    """torchlibrosa's Spectrogram takes any librosa window specification (stft.py: get_window(window, win_length,
+    fftbins=True) + pad_center): names, (name, parameter) tuples, arrays and callables, with win_length <= n_fft.
+    Checked against the fp64 transform with the same window, unfused and fused.  Parity unpinned: the reference itself only
+    ever asks for 'hann' (htsat.py:453-455)."""
+    import sed_amd
+    from scipy.signal import get_window
+    dev = _dev()
+    x = of.synth_batch(3, 40000, 32000, first=11)
+    xt = torch.from_numpy(x).to(dev)
+    cases = [("hamming", 1024, 1024, 320), ("blackman", 1024, 800, 256), (("kaiser", 8.0), 512, 400, 160),
+             (("tukey", 0.25), 2048, 2048, 512), ("boxcar", 1024, 1024, 320)]
+    for window, n_fft, win_length, hop in cases:
+        wfull = of.pad_center(get_window(window, win_length, fftbins=True).astype(np.float64), n_fft)
+        sp = sed_amd.Spectrogram(n_fft=n_fft, hop_length=hop, win_length=win_length, window=window).to(dev)
+        p = sp(xt)[:, 0].cpu().numpy().astype(np.float64)
+        gold_p = of.power_spectrogram_gold(x, n_fft, hop, win_length, window_full=wfull)
+        assert p.shape == gold_p.shape
+        # relative to the frame's largest bin; a window without a taper leaks more and leaves less dynamic range
+        assert np.max(np.abs(p - gold_p) / np.maximum(gold_p.max(axis=-1, keepdims=True), 1e-30)) < 2e-6, window
+        # the tables a checkpoint would carry are those of torchlibrosa's recipe for that window
+        wr, wi = of.torchlibrosa_conv_weights(n_fft, wfull)
+        assert np.array_equal(sp.stft.conv_real.weight.cpu().numpy(), wr)
+        assert np.array_equal(sp.stft.conv_imag.weight.cpu().numpy(), wi)
+        lm = sed_amd.LogmelFilterBank(sr=32000, n_fft=n_fft, n_mels=64, fmin=50, fmax=14000, top_db=None).to(dev)
+        fused = sed_amd.LogMelFrontend.from_torchlibrosa(sp, lm)(xt).cpu().numpy()
+        melW = of.librosa_mel(32000, n_fft, 64, 50, 14000).T
+        gold = of.power_to_db(gold_p @ melW.astype(np.float64))[:, None]
+        ref32 = of.power_to_db(of.power_spectrogram_ref32(x, n_fft, hop, win_length, window_full=wfull) @ melW)[:, None]
+        _check(fused, gold, ref32, NEAR_DB)
+        assert torch.max(torch.abs(torch.from_numpy(fused).to(dev) - lm(sp(xt)))).item() < 1e-4
+    # an array and a callable give what the name gives
+    ham = get_window("hamming", 1024, fftbins=True)
+    want = sed_amd.Spectrogram(n_fft=1024, hop_length=320, window="hamming")(xt)
+    assert torch.equal(sed_amd.Spectrogram(n_fft=1024, hop_length=320, window=ham)(xt), want)
+    assert torch.equal(sed_amd.Spectrogram(n_fft=1024, hop_length=320, window=lambda n: get_window("hamming", n))(xt), want)
+    with pytest.raises(ValueError):
+        sed_amd.Spectrogram(n_fft=1024, hop_length=320, window=ham[:-1])
+    # a state_dict saved with one window does not load into a module built with another
+    a = sed_amd.Spectrogram(n_fft=1024, hop_length=320, window="hamming")
+    b = sed_amd.Spectrogram(n_fft=1024, hop_length=320, window="hann")
+    with pytest.raises(RuntimeError):
+        b.load_state_dict(a.state_dict())
+    b2 = sed_amd.Spectrogram(n_fft=1024, hop_length=320, window="hamming")
+    b2.load_state_dict(a.state_dict())
+
+
 def test_yamnet_features():
     import sed_amd
     _dev()
