@@ -3,7 +3,9 @@
 # usage: resource_usage.sh [file.hip] [extra hipcc flags]
 f=${1:-sed_frontend.hip}
 shift
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I../../include "$@" -c "$f" -o /dev/null \
+# the decoders and the resampler are built without fp contraction, as in the Makefile
+case "$f" in *sed_frontend.hip) nc= ;; *) nc=-ffp-contract=off ;; esac
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I../../include $nc "$@" -c "$f" -o /dev/null \
   -Rpass-analysis=kernel-resource-usage 2>&1 | python3 -c '
 import re, subprocess, sys
 rows, cur = [], None

@@ -211,6 +211,53 @@ __global__ void __launch_bounds__(512) resample_dma_kernel(const ResampleParams 
     asm volatile("" : "+v"(lo_here));  // addresses derived from it are formed per tile, not kept in registers across tiles
     const float* mine = cur + lo_here;
     constexpr int S = R >= 8 ? 2 : 4;
+#ifndef SED_RS_NO_ASM_PIPE
+    // Hand-placed LDS reads and waits: with an LDS-DMA transfer in flight the compiler waits for ALL outstanding LDS
+    // reads before every use (it cannot order them against the transfer), which would serialise fetch and arithmetic.
+    // The reads return in order, so after the reads of the next step are issued, waiting until only those are
+    // outstanding makes this step's samples valid.  Nothing else of the wavefront uses the LDS counter in this loop.
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    static_assert(S % 2 == 0, "taps are read two at a time");
+    f2 xp[2][S / 2][R];
+    unsigned base[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) base[r] = (unsigned)(size_t)(mine + r * p.qstep);
+    auto load = [&](int buf, int i0) {
+#pragma unroll
+      for (int e = 0; e < S / 2; ++e)
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+          asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3"
+                       : "=v"(xp[buf][e][r]) : "v"(base[r]), "n"(i0 + 2 * e), "n"(i0 + 2 * e + 1) : "memory");
+    };
+    constexpr int kPerStep = (S / 2) * R;  // read instructions of one step
+    static_assert(kPerStep <= 15, "the wait counter holds 15");
+    load(0, 0);
+#pragma unroll
+    for (int i0 = 0; i0 < TP; i0 += S) {  // oldest input first, as scipy accumulates
+      const int cur_buf = (i0 / S) & 1;
+      if (i0 + S < TP) {
+        load(cur_buf ^ 1, i0 + S);
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(kPerStep) : "memory");
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      // (the samples pass through an empty statement so that no use of them can be placed above the wait)
+#pragma unroll
+      for (int e = 0; e < S / 2; ++e)
+#pragma unroll
+        for (int r = 0; r < R; ++r) asm volatile("" : "+v"(xp[cur_buf][e][r]));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int e = 0; e < S; ++e)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const f2 pr = xp[cur_buf][e / 2][r];
+          acc[r] = __fadd_rn(acc[r], __fmul_rn((e & 1) ? pr.y : pr.x, c[TP - 1 - i0 - e]));
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#else
     float xv[2][S][R];
     auto load = [&](int buf, int i0) {
 #pragma unroll
@@ -230,6 +277,7 @@ __global__ void __launch_bounds__(512) resample_dma_kernel(const ResampleParams 
           acc[r] = __fadd_rn(acc[r], __fmul_rn(xv[(i0 / S) & 1][e][r], c[TP - 1 - i0 - e]));
       __builtin_amdgcn_sched_barrier(0);
     }
+#endif
 #pragma unroll
     for (int r = 0; r < R; ++r) yb[r * NT + o] = acc[r];
     // the next span has had the whole tile to land; the stores below are issued after this wait, so it never waits for them
@@ -361,29 +409,26 @@ extern "C" int sed_resampler_create(int32_t orig_sr, int32_t target_sr, sed_resa
   {
     // thread -> output assignment of a group: every wavefront gets outputs whose first LDS read falls into 64 different
     // banks (lane = bank; lanes i and i + 32 then also differ modulo 32), as far as the residues allow; later taps and
-    // groups shift every lane by the same amount, so the property holds for all reads.  Leftovers fill the holes.
+    // groups shift every lane by the same amount, so the property holds for all reads.
     const int NT = r->threads;
     std::vector<std::vector<int>> bucket(64);
     for (int o = NT - 1; o >= 0; --o) {
       const int pos = (int)((((int64_t)o + r->n_pre_remove) * down) / up) - r->q0;
       bucket[pos % 64].push_back(o);
     }
+    // wavefront by wavefront, one output from every residue that still has some, round and round until the 64 lanes
+    // are filled: a residue that must repeat within a wavefront (hops of an even number of samples reach only half of the
+    // banks) repeats as rarely as possible
     r->assign.assign(NT, -1);
+    int next_bucket = 0;
     for (int t = 0; t < NT; ++t) {
-      auto& bk = bucket[t % 64];
-      if (!bk.empty()) {
-        r->assign[t] = bk.back();
-        bk.pop_back();
-      }
+      if (t % 64 == 0) next_bucket = 0;
+      for (int tries = 0; tries < 64 && bucket[next_bucket].empty(); ++tries) next_bucket = (next_bucket + 1) % 64;
+      auto& bk = bucket[next_bucket];
+      r->assign[t] = bk.back();
+      bk.pop_back();
+      next_bucket = (next_bucket + 1) % 64;
     }
-    std::vector<int> rest;
-    for (auto& bk : bucket)
-      for (int o : bk) rest.push_back(o);
-    for (int t = 0; t < NT; ++t)
-      if (r->assign[t] < 0) {
-        r->assign[t] = rest.back();
-        rest.pop_back();
-      }
   }
   int rc = rs_status(hipGetDevice(&r->device));
   hipDeviceProp_t prop;
