@@ -683,7 +683,15 @@ stft_mel_kernel(const FrontParams p) {
         }
       }
       SED_STAMP(0)
-      if (!SED_SKIP(1024)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // The wait for the span is the compiler's own instruction (vmcnt 0, the other counters left alone), not inline
+      // assembly: the compiler keeps a transfer into LDS on its books until it sees it waited for, and while one is
+      // outstanding it turns every wait for an LDS read into a wait for all of them, which undoes the ordering of the table
+      // reads below (issued well ahead of their use) for the whole loop.
+      if (!SED_SKIP(1024)) {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        asm volatile("" ::: "memory");
+      }
       wave_phase_fence();
       SED_STAMP(1)
       if constexpr (!SPEC_OUT) {
