@@ -577,13 +577,19 @@ def main():
 
     h2d = measure_h2d(x) if rank == 0 else None
 
-    traffic = None
+    # HBM bytes per launch from the PMC passes kept under profiles/ (collected with this command, not in this run), and
+    # whether the kernel sources still are the ones that library was built from
+    traffic, traffic_current = None, None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("htsat_b256_fp32", {}).get("hbm_bytes_per_launch")
+            ent = json.load(open(tpath)).get("htsat_b256_fp32", {})
+            traffic = ent.get("hbm_bytes_per_launch")
+            sys.path.insert(0, os.path.join(ROOT, "profiles", "tools"))
+            from update_traffic import kernel_source_fingerprint
+            traffic_current = ent.get("kernel_source_fingerprint") == kernel_source_fingerprint()
         except Exception:
-            traffic = None
+            traffic, traffic_current = None, None
 
     res = {
         "metric": "log-mel audio-hours/sec", "value": value, "unit": "audio-hours/s", "n_gpus": world,
@@ -603,6 +609,7 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "stft_mel_kernel<n_fft=1024, power, mel+log>", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": "profiles/hbm_traffic.json (rocprofv3 PMC passes of this command, not this run)",
+                     "traffic_is_of_these_kernel_sources": traffic_current,
                      "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms,
                      "kernel_ms_p10_p50_p90": [pct(0.1), pct(0.5), pct(0.9)]},
     }

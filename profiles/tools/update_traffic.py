@@ -1,0 +1,39 @@
+"""Writes profiles/hbm_traffic.json from a summary of the PMC passes (profiles/summarize.py output), together with a
+fingerprint of the kernel sources the profiled library was built from, so that bench.py can tell when the figure it quotes
+no longer belongs to the kernel it runs:  python profiles/tools/update_traffic.py gpurun_out/r03_summary.json "<library note>" """
+import hashlib
+import json
+import os
+import sys
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
+KERNEL_SOURCES = ("sound-event-detection_amd/csrc/sed_frontend.hip", "sound-event-detection_amd/csrc/fft_core.h",
+                  "sound-event-detection_amd/csrc/tables.h")
+
+
+def kernel_source_fingerprint() -> str:
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def main():
+    summary, note = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "")
+    d = json.load(open(summary))
+    key = [k for k in d["pmc"] if "stft_mel" in k][0]
+    m = d["pmc"][key]["mean_per_dispatch"]
+    fetch, write = m["FETCH_SIZE"] * 1024 * 2, m["WRITE_SIZE"] * 1024
+    out = {"htsat_b256_fp32": {
+        "hbm_bytes_per_launch": fetch + write, "fetch_bytes_corrected": fetch, "write_bytes": write,
+        "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (KB units); FETCH_SIZE doubled per the "
+                "gfx950 correction for wide coalesced streaming reads",
+        "source": "profiles/r03_stft_mel.json", "library": note,
+        "kernel_source_fingerprint": kernel_source_fingerprint()}}
+    json.dump(out, open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
