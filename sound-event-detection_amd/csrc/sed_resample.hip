@@ -131,7 +131,8 @@ __global__ void __launch_bounds__(512) resample_kernel(const ResampleParams p) {
 
 // The same computation for fp32 input with the span moved from global memory straight into LDS (LDS-DMA, 4 bytes per
 // lane so that any sample alignment works), double buffered: the span of tile i+1 is in flight while tile i is computed,
-// no staging registers, one workgroup barrier per tile.  blockDim.x is a multiple of 64.
+// no staging registers, one workgroup barrier per tile.  blockDim.x is a multiple of 32 (a last wavefront of 32 threads
+// moves 32 samples per round).
 //   buffers: xs[2][span_stride] (span_stride = DMA rounds x blockDim.x >= stage_count), ys[2][R][blockDim.x]
 template <int TP, int R, typename T>
 __global__ void __launch_bounds__(512) resample_dma_kernel(const ResampleParams p) {
@@ -378,8 +379,20 @@ extern "C" int sed_resampler_create(int32_t orig_sr, int32_t target_sr, sed_resa
     return SED_ERR_BAD_ARG;
   }
   // P periods of `up` outputs per group: about 256 threads; R groups per tile, as many of {4, 2, 1} as the staging
-  // registers and 48 KB of LDS allow
+  // registers and 64 KB of LDS allow
   r->periods = std::max(1, std::min(max_threads / up, (256 + up - 1) / up));
+  {
+    // The wavefronts of a workgroup go to the four SIMDs of a CU in turn, starting from the first: a workgroup of 5
+    // wavefronts puts two on the first SIMD, and two such workgroups fill its share of the registers while the other
+    // three SIMDs are half empty (measured: 7 resident wavefronts per CU for 320 threads of 110 registers).  Prefer, among
+    // the period counts of at least 256 threads, the one whose wavefronts spread most evenly over the SIMDs.
+    double best = 1e30;
+    for (int P = r->periods; P >= 1 && P <= max_threads / up; ++P) {
+      const int waves = (up * P + 63) / 64;
+      const double imbalance = (double)((waves + 3) / 4) / (waves / 4.0) + 1e-3 * P;  // most loaded SIMD / average
+      if (imbalance < best - 1e-9) { best = imbalance; r->periods = P; }
+    }
+  }
   r->threads = up * r->periods;
   r->q0 = (int32_t)(((int64_t)r->n_pre_remove * down) / up);
   r->qstep = r->periods * down;
@@ -387,7 +400,7 @@ extern "C" int sed_resampler_create(int32_t orig_sr, int32_t target_sr, sed_resa
   r->groups = 0;
   for (int R : {8, 4, 2, 1}) {
     const int64_t count = (int64_t)(R - 1) * r->qstep + span1;
-    if (r->groups == 0 && count <= (int64_t)stage_regs(R) * r->threads && (count + (int64_t)R * r->threads) * 4 <= 48 * 1024) {
+    if (r->groups == 0 && count <= (int64_t)stage_regs(R) * r->threads && (count + (int64_t)R * r->threads) * 4 <= 64 * 1024) {
       r->groups = R;
       r->stage_count = (int32_t)count;
     }
@@ -396,11 +409,11 @@ extern "C" int sed_resampler_create(int32_t orig_sr, int32_t target_sr, sed_resa
     delete r;
     return SED_ERR_BAD_ARG;
   }
-  if (r->threads % 64 == 0)
-    for (int R : {4, 2, 1}) {  // two span buffers and two output buffers in at most 48 KB
+  if (r->threads % 32 == 0)  // (a last wavefront with 32 threads moves 32 samples per round: the rounds stay contiguous)
+    for (int R : {4, 2, 1}) {  // two span buffers and two output buffers in at most 64 KB: two workgroups per CU
       const int64_t count = (int64_t)(R - 1) * r->qstep + span1;
       const int64_t rounds = (count + r->threads - 1) / r->threads;
-      if (r->dma_groups == 0 && (2 * rounds * r->threads + 2 * (int64_t)R * r->threads) * 4 <= 48 * 1024) {
+      if (r->dma_groups == 0 && (2 * rounds * r->threads + 2 * (int64_t)R * r->threads) * 4 <= 64 * 1024) {
         r->dma_groups = R;
         r->dma_stage_count = (int32_t)count;
         r->dma_rounds = (int32_t)rounds;
