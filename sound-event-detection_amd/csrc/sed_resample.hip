@@ -134,7 +134,11 @@ __global__ void __launch_bounds__(512) resample_kernel(const ResampleParams p) {
 // no staging registers, one workgroup barrier per tile.  blockDim.x is a multiple of 32 (a last wavefront of 32 threads
 // moves 32 samples per round).
 //   buffers: xs[2][span_stride] (span_stride = DMA rounds x blockDim.x >= stage_count), ys[2][R][blockDim.x]
-template <int TP, int R, typename T>
+// B64: every lane starts on an even sample (an odd first sample is skipped: its coefficient is the table's zero padding,
+// and the lane's coefficients move up by one), so the tap loop reads its sample pairs with 8-byte LDS reads, which the
+// LDS serves at twice the rate of two 4-byte reads per lane.  Needs an even number of input samples per group and at
+// least one zero coefficient of padding per phase.
+template <int TP, int R, typename T, bool B64>
 __global__ void __launch_bounds__(512) resample_dma_kernel(const ResampleParams p) {
   extern __shared__ __align__(16) float lds[];
   const int t = threadIdx.x, NT = blockDim.x;
@@ -144,10 +148,17 @@ __global__ void __launch_bounds__(512) resample_dma_kernel(const ResampleParams 
   const int o = p.assign[t];
   const int64_t tt = ((int64_t)o + p.n_pre_remove) * p.down;
   const int phase = (int)(tt % p.up);
-  const int lo = (int)(tt / p.up) - p.q0;
+  int lo = (int)(tt / p.up) - p.q0;
   float c[TP];
+  if constexpr (B64) {
+    const int odd = lo & 1;
+    lo += odd;
 #pragma unroll
-  for (int j = 0; j < TP; ++j) c[j] = p.table[phase * TP + j];
+    for (int j = 0; j < TP; ++j) c[j] = j >= odd ? p.table[phase * TP + j - odd] : 0.0f;
+  } else {
+#pragma unroll
+    for (int j = 0; j < TP; ++j) c[j] = p.table[phase * TP + j];
+  }
   const int total = (int)p.B * p.tiles;
   // issue: wave w moves samples [64 (w + n NT/64), +64) of the span in round n; addresses are clamped into the clip
   auto issue = [&](int work, float* dstbuf) {
@@ -227,9 +238,13 @@ __global__ void __launch_bounds__(512) resample_dma_kernel(const ResampleParams 
 #pragma unroll
       for (int e = 0; e < S / 2; ++e)
 #pragma unroll
-        for (int r = 0; r < R; ++r)
-          asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3"
-                       : "=v"(xp[buf][e][r]) : "v"(base[r]), "n"(i0 + 2 * e), "n"(i0 + 2 * e + 1) : "memory");
+        for (int r = 0; r < R; ++r) {
+          if constexpr (B64)
+            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(xp[buf][e][r]) : "v"(base[r]), "n"(4 * (i0 + 2 * e)) : "memory");
+          else
+            asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3"
+                         : "=v"(xp[buf][e][r]) : "v"(base[r]), "n"(i0 + 2 * e), "n"(i0 + 2 * e + 1) : "memory");
+        }
     };
     constexpr int kPerStep = (S / 2) * R;  // read instructions of one step
     static_assert(kPerStep <= 15, "the wait counter holds 15");
@@ -324,6 +339,9 @@ struct sed_resampler {
   int32_t dma_groups = 0, dma_stage_count = 0, dma_rounds = 0;  // LDS-DMA variant (fp32 input), 0 groups: not available
   std::vector<int32_t> assign;    // [threads] output of a group owned by each thread
   int32_t* d_assign = nullptr;
+  bool b64 = false;               // the LDS-DMA variant reads sample pairs from even offsets (8-byte LDS reads)
+  std::vector<int32_t> assign64;  // its thread -> output table
+  int32_t* d_assign64 = nullptr;
   int device = 0, num_cus = 256;
   std::vector<float> table_host;  // [up][taps]
   float* d_table = nullptr;       // [up][tp]
@@ -419,6 +437,37 @@ extern "C" int sed_resampler_create(int32_t orig_sr, int32_t target_sr, sed_resa
         r->dma_rounds = (int32_t)rounds;
       }
     }
+  r->b64 = r->dma_groups > 0 && r->qstep % 2 == 0 && r->taps < r->tp;
+  if (r->b64) {
+    // a lane that skips an odd first sample reads one sample past its window (coefficient 0): one more staged sample
+    const int count = r->dma_stage_count + 1, rounds = (count + r->threads - 1) / r->threads;
+    if ((2 * (int64_t)rounds * r->threads + 2 * (int64_t)r->dma_groups * r->threads) * 4 <= 64 * 1024) {
+      r->dma_stage_count = count;
+      r->dma_rounds = rounds;
+    } else {
+      r->b64 = false;
+    }
+  }
+  if (r->b64) {
+    // thread -> output table for 8-byte reads: the 32 lanes the LDS serves together start on 32 different bank pairs,
+    // as far as the residues allow
+    const int NT = r->threads;
+    std::vector<std::vector<int>> bucket(32);
+    for (int o = NT - 1; o >= 0; --o) {
+      int pos = (int)((((int64_t)o + r->n_pre_remove) * down) / up) - r->q0;
+      pos += pos & 1;
+      bucket[(pos / 2) % 32].push_back(o);
+    }
+    r->assign64.assign(NT, -1);
+    int nb = 0;
+    for (int t = 0; t < NT; ++t) {
+      if (t % 32 == 0) nb = 0;
+      for (int tries = 0; tries < 32 && bucket[nb].empty(); ++tries) nb = (nb + 1) % 32;
+      r->assign64[t] = bucket[nb].back();
+      bucket[nb].pop_back();
+      nb = (nb + 1) % 32;
+    }
+  }
   {
     // thread -> output assignment of a group: every wavefront gets outputs whose first LDS read falls into 64 different
     // banks (lane = bank; lanes i and i + 32 then also differ modulo 32), as far as the residues allow; later taps and
@@ -454,9 +503,14 @@ extern "C" int sed_resampler_create(int32_t orig_sr, int32_t target_sr, sed_resa
   if (!rc) rc = rs_status(hipMemcpy(r->d_table, padded.data(), padded.size() * sizeof(float), hipMemcpyHostToDevice));
   if (!rc) rc = rs_status(hipMalloc((void**)&r->d_assign, r->assign.size() * sizeof(int32_t)));
   if (!rc) rc = rs_status(hipMemcpy(r->d_assign, r->assign.data(), r->assign.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (!rc && r->b64) {
+    rc = rs_status(hipMalloc((void**)&r->d_assign64, r->assign64.size() * sizeof(int32_t)));
+    if (!rc) rc = rs_status(hipMemcpy(r->d_assign64, r->assign64.data(), r->assign64.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
   if (rc) {
     if (r->d_table) (void)hipFree(r->d_table);
     if (r->d_assign) (void)hipFree(r->d_assign);
+    if (r->d_assign64) (void)hipFree(r->d_assign64);
     delete r;
     return rc;
   }
@@ -468,6 +522,7 @@ extern "C" void sed_resampler_destroy(sed_resampler* r) {
   if (!r) return;
   if (r->d_table) (void)hipFree(r->d_table);
   if (r->d_assign) (void)hipFree(r->d_assign);
+  if (r->d_assign64) (void)hipFree(r->d_assign64);
   delete r;
 }
 
@@ -500,18 +555,21 @@ static int launch_resample_r(const ResampleParams& p, int32_t pcm_kind, int thre
   return rs_status(hipGetLastError());
 }
 
-template <int TP, typename T>
+template <int TP, typename T, bool B64>
 static int launch_resample_dma_t(int groups, const ResampleParams& p, int threads, size_t lds, int blocks, hipStream_t stream) {
-  if (groups == 4) hipLaunchKernelGGL((resample_dma_kernel<TP, 4, T>), dim3(blocks), dim3(threads), lds, stream, p);
-  else if (groups == 2) hipLaunchKernelGGL((resample_dma_kernel<TP, 2, T>), dim3(blocks), dim3(threads), lds, stream, p);
-  else hipLaunchKernelGGL((resample_dma_kernel<TP, 1, T>), dim3(blocks), dim3(threads), lds, stream, p);
+  if (groups == 4) hipLaunchKernelGGL((resample_dma_kernel<TP, 4, T, B64>), dim3(blocks), dim3(threads), lds, stream, p);
+  else if (groups == 2) hipLaunchKernelGGL((resample_dma_kernel<TP, 2, T, B64>), dim3(blocks), dim3(threads), lds, stream, p);
+  else hipLaunchKernelGGL((resample_dma_kernel<TP, 1, T, B64>), dim3(blocks), dim3(threads), lds, stream, p);
   return rs_status(hipGetLastError());
 }
 
 template <int TP>
-static int launch_resample_dma(int groups, const ResampleParams& p, int threads, size_t lds, int blocks, hipStream_t stream) {
-  if (p.div == 0.0f) return launch_resample_dma_t<TP, float>(groups, p, threads, lds, blocks, stream);
-  return launch_resample_dma_t<TP, int16_t>(groups, p, threads, lds, blocks, stream);
+static int launch_resample_dma(int groups, bool b64, const ResampleParams& p, int threads, size_t lds, int blocks, hipStream_t stream) {
+  if (p.div == 0.0f)
+    return b64 ? launch_resample_dma_t<TP, float, true>(groups, p, threads, lds, blocks, stream)
+               : launch_resample_dma_t<TP, float, false>(groups, p, threads, lds, blocks, stream);
+  return b64 ? launch_resample_dma_t<TP, int16_t, true>(groups, p, threads, lds, blocks, stream)
+             : launch_resample_dma_t<TP, int16_t, false>(groups, p, threads, lds, blocks, stream);
 }
 
 template <int TP>
@@ -582,7 +640,8 @@ extern "C" int sed_resampler_forward(const sed_resampler* r, const void* pcm, in
   p.q0 = r->q0;
   p.qstep = r->qstep;
   p.stage_count = dma ? r->dma_stage_count : r->stage_count;
-  p.assign = r->d_assign;
+  const bool b64 = dma && r->b64;
+  p.assign = b64 ? r->d_assign64 : r->d_assign;
   p.n_iter = dma ? r->dma_rounds : (r->stage_count + threads - 1) / threads;
   p.span_stride = r->dma_rounds * threads;
   p.div3 = (pcm_kind == SED_PCM_I16 && dma && three_step_division_is_exact(pcm_divisor)) ? 1 : 0;
@@ -593,14 +652,14 @@ extern "C" int sed_resampler_forward(const sed_resampler* r, const void* pcm, in
   const int blocks = (int)std::min<int64_t>(total, (int64_t)r->num_cus * std::max(1, 2048 / threads));
   hipStream_t s = (hipStream_t)stream;
   if (dma) switch (r->tp) {
-      case 16: return launch_resample_dma<16>(R, p, threads, lds, blocks, s);
-      case 32: return launch_resample_dma<32>(R, p, threads, lds, blocks, s);
-      case 48: return launch_resample_dma<48>(R, p, threads, lds, blocks, s);
-      case 56: return launch_resample_dma<56>(R, p, threads, lds, blocks, s);
-      case 60: return launch_resample_dma<60>(R, p, threads, lds, blocks, s);
-      case 64: return launch_resample_dma<64>(R, p, threads, lds, blocks, s);
-      case 96: return launch_resample_dma<96>(R, p, threads, lds, blocks, s);
-      default: return launch_resample_dma<128>(R, p, threads, lds, blocks, s);
+      case 16: return launch_resample_dma<16>(R, b64, p, threads, lds, blocks, s);
+      case 32: return launch_resample_dma<32>(R, b64, p, threads, lds, blocks, s);
+      case 48: return launch_resample_dma<48>(R, b64, p, threads, lds, blocks, s);
+      case 56: return launch_resample_dma<56>(R, b64, p, threads, lds, blocks, s);
+      case 60: return launch_resample_dma<60>(R, b64, p, threads, lds, blocks, s);
+      case 64: return launch_resample_dma<64>(R, b64, p, threads, lds, blocks, s);
+      case 96: return launch_resample_dma<96>(R, b64, p, threads, lds, blocks, s);
+      default: return launch_resample_dma<128>(R, b64, p, threads, lds, blocks, s);
     }
   switch (r->tp) {
     case 16: return launch_resample<16>(R, p, pcm_kind, threads, lds, blocks, s);
