@@ -138,8 +138,10 @@ __global__ void __launch_bounds__(512) resample_kernel(const ResampleParams p) {
 // and the lane's coefficients move up by one), so the tap loop reads its sample pairs with 8-byte LDS reads, which the
 // LDS serves at twice the rate of two 4-byte reads per lane.  Needs an even number of input samples per group and at
 // least one zero coefficient of padding per phase.
-template <int TP, int R, typename T, bool B64>
-__global__ void __launch_bounds__(512) resample_dma_kernel(const ResampleParams p) {
+// MAXT: the largest workgroup the kernel is built for (512: up to 256 registers; 1024: up to 128, phases of at most 64
+// coefficients).
+template <int TP, int R, typename T, bool B64, int MAXT>
+__global__ void __launch_bounds__(MAXT) resample_dma_kernel(const ResampleParams p) {
   extern __shared__ __align__(16) float lds[];
   const int t = threadIdx.x, NT = blockDim.x;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
@@ -403,12 +405,26 @@ extern "C" int sed_resampler_create(int32_t orig_sr, int32_t target_sr, sed_resa
     // The wavefronts of a workgroup go to the four SIMDs of a CU in turn, starting from the first: a workgroup of 5
     // wavefronts puts two on the first SIMD, and two such workgroups fill its share of the registers while the other
     // three SIMDs are half empty (measured: 7 resident wavefronts per CU for 320 threads of 110 registers).  Prefer, among
-    // the period counts of at least 256 threads, the one whose wavefronts spread most evenly over the SIMDs.
+    // the period counts of at least 256 threads, the one whose wavefronts spread most evenly over the SIMDs, and one
+    // whose group advances by an even number of input samples (8-byte LDS reads, see resample_dma_kernel).  Workgroups of
+    // more than 512 threads exist for the LDS-DMA kernel only (phases of at most 64 coefficients, whole half wavefronts,
+    // its buffers within 64 KB).
+    auto dma_fits = [&](int P) {
+      const int64_t threads = (int64_t)up * P, qstep = (int64_t)P * down;
+      if (threads % 32 != 0) return false;
+      const int64_t count = ((threads - 1 + r->n_pre_remove) * down) / up - ((int64_t)r->n_pre_remove * down) / up + r->tp + 1;
+      const int64_t rounds = (count + threads - 1) / threads;
+      (void)qstep;
+      return (2 * rounds * threads + 2 * threads) * 4 <= 64 * 1024;  // one group per tile at least
+    };
     double best = 1e30;
-    for (int P = r->periods; P >= 1 && P <= max_threads / up; ++P) {
+    const int first = r->periods;
+    for (int P = first; P >= 1 && (int64_t)up * P <= 1024; ++P) {
+      if (up * P > max_threads && !(r->tp <= 64 && dma_fits(P))) continue;
       const int waves = (up * P + 63) / 64;
-      const double imbalance = (double)((waves + 3) / 4) / (waves / 4.0) + 1e-3 * P;  // most loaded SIMD / average
-      if (imbalance < best - 1e-9) { best = imbalance; r->periods = P; }
+      const double score = (double)((waves + 3) / 4) / (waves / 4.0)             // most loaded SIMD / average
+                           - (((int64_t)P * down) % 2 == 0 ? 0.2 : 0.0) + 1e-3 * P;
+      if (score < best - 1e-9) { best = score; r->periods = P; }
     }
   }
   r->threads = up * r->periods;
@@ -423,7 +439,7 @@ extern "C" int sed_resampler_create(int32_t orig_sr, int32_t target_sr, sed_resa
       r->stage_count = (int32_t)count;
     }
   }
-  if (r->groups == 0) {
+  if (r->groups == 0 && r->threads <= max_threads) {
     delete r;
     return SED_ERR_BAD_ARG;
   }
@@ -555,21 +571,28 @@ static int launch_resample_r(const ResampleParams& p, int32_t pcm_kind, int thre
   return rs_status(hipGetLastError());
 }
 
-template <int TP, typename T, bool B64>
+template <int TP, typename T, bool B64, int MAXT>
 static int launch_resample_dma_t(int groups, const ResampleParams& p, int threads, size_t lds, int blocks, hipStream_t stream) {
-  if (groups == 4) hipLaunchKernelGGL((resample_dma_kernel<TP, 4, T, B64>), dim3(blocks), dim3(threads), lds, stream, p);
-  else if (groups == 2) hipLaunchKernelGGL((resample_dma_kernel<TP, 2, T, B64>), dim3(blocks), dim3(threads), lds, stream, p);
-  else hipLaunchKernelGGL((resample_dma_kernel<TP, 1, T, B64>), dim3(blocks), dim3(threads), lds, stream, p);
+  if (groups == 4) hipLaunchKernelGGL((resample_dma_kernel<TP, 4, T, B64, MAXT>), dim3(blocks), dim3(threads), lds, stream, p);
+  else if (groups == 2) hipLaunchKernelGGL((resample_dma_kernel<TP, 2, T, B64, MAXT>), dim3(blocks), dim3(threads), lds, stream, p);
+  else hipLaunchKernelGGL((resample_dma_kernel<TP, 1, T, B64, MAXT>), dim3(blocks), dim3(threads), lds, stream, p);
   return rs_status(hipGetLastError());
+}
+
+template <int TP, int MAXT>
+static int launch_resample_dma_m(int groups, bool b64, const ResampleParams& p, int threads, size_t lds, int blocks, hipStream_t stream) {
+  if (p.div == 0.0f)
+    return b64 ? launch_resample_dma_t<TP, float, true, MAXT>(groups, p, threads, lds, blocks, stream)
+               : launch_resample_dma_t<TP, float, false, MAXT>(groups, p, threads, lds, blocks, stream);
+  return b64 ? launch_resample_dma_t<TP, int16_t, true, MAXT>(groups, p, threads, lds, blocks, stream)
+             : launch_resample_dma_t<TP, int16_t, false, MAXT>(groups, p, threads, lds, blocks, stream);
 }
 
 template <int TP>
 static int launch_resample_dma(int groups, bool b64, const ResampleParams& p, int threads, size_t lds, int blocks, hipStream_t stream) {
-  if (p.div == 0.0f)
-    return b64 ? launch_resample_dma_t<TP, float, true>(groups, p, threads, lds, blocks, stream)
-               : launch_resample_dma_t<TP, float, false>(groups, p, threads, lds, blocks, stream);
-  return b64 ? launch_resample_dma_t<TP, int16_t, true>(groups, p, threads, lds, blocks, stream)
-             : launch_resample_dma_t<TP, int16_t, false>(groups, p, threads, lds, blocks, stream);
+  if (threads <= 512) return launch_resample_dma_m<TP, 512>(groups, b64, p, threads, lds, blocks, stream);
+  if constexpr (TP <= 64) return launch_resample_dma_m<TP, 1024>(groups, b64, p, threads, lds, blocks, stream);
+  else return SED_ERR_BAD_ARG;
 }
 
 template <int TP>
@@ -622,6 +645,7 @@ extern "C" int sed_resampler_forward(const sed_resampler* r, const void* pcm, in
   static const bool no_dma = getenv("SED_RS_NO_DMA") != nullptr, no_dma16 = getenv("SED_RS_NO_DMA16") != nullptr;
   dma = dma && !no_dma && (pcm_kind == SED_PCM_F32 || !no_dma16);
 #endif
+  if (!dma && r->threads > 512) return SED_ERR_BAD_ARG;  // (a PCM pointer that is not a multiple of its sample size)
   const int threads = r->threads, R = dma ? r->dma_groups : r->groups;
   ResampleParams p;
   p.pcm = pcm;
