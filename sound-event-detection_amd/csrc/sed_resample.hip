@@ -402,9 +402,10 @@ extern "C" int sed_resampler_create(int32_t orig_sr, int32_t target_sr, sed_resa
   // registers and 64 KB of LDS allow
   r->periods = std::max(1, std::min(max_threads / up, (256 + up - 1) / up));
   {
-    // The wavefronts of a workgroup go to the four SIMDs of a CU in turn, starting from the first: a workgroup of 5
-    // wavefronts puts two on the first SIMD, and two such workgroups fill its share of the registers while the other
-    // three SIMDs are half empty (measured: 7 resident wavefronts per CU for 320 threads of 110 registers).  Prefer, among
+    // Workgroups whose wavefront count is not a multiple of four leave the CU half empty: with 320 threads (5 wavefronts) of
+    // 110 registers a CU held 7 wavefronts on average instead of the 15 its registers and LDS allow, with 480 threads (8
+    // wavefronts) it holds 14 (SQ_WAVE_CYCLES against GRBM_GUI_ACTIVE) -- as if the wavefronts of every workgroup went to the
+    // four SIMDs in turn starting from the first, so that two 5-wavefront workgroups fill the first SIMD's registers.  Prefer, among
     // the period counts of at least 256 threads, the one whose wavefronts spread most evenly over the SIMDs, and one
     // whose group advances by an even number of input samples (8-byte LDS reads, see resample_dma_kernel).  Workgroups of
     // more than 512 threads exist for the LDS-DMA kernel only (phases of at most 64 coefficients, whole half wavefronts,
