@@ -126,6 +126,13 @@ def test_logmel_of_events_equals_cut_then_front_end():
         clips, lens = sed_amd.cut_events(rows, sr, events, cap=96000, pcm_divisor=32768.0)
         got, glens = sed_amd.logmel_of_events(fe16, rows, sr, events, 96000)
         assert torch.equal(got, fe32(clips)) and torch.equal(glens, lens)
+    # segment tables already on the device are taken as they are; lengths beyond the row are cut to it inside the kernel
+    flat = x[:, :n].contiguous()
+    off = torch.tensor([0, 1 * n + 4000, 3 * n + 12345, 5 * n + 200000], dtype=torch.int64, device=dev)
+    full = torch.tensor([50000, 96000, 120000, 70000], dtype=torch.int32, device=dev)
+    got, _ = fe32.forward_segments(flat, off, full, 96000)
+    want, _ = fe32.forward_segments(flat, off.cpu().numpy(), full.cpu().numpy(), 96000)    # host arrays: clamped on the host
+    assert torch.equal(got, want)
     # no events, and refusals
     empty, elens = sed_amd.logmel_of_events(fe32, x[:, :n], sr, [], 96000)
     assert empty.shape == (0, fe32.num_frames(96000, dev), 64) and elens.numel() == 0
