@@ -114,6 +114,19 @@ def time_kernel(fn, steps, warmup):
     return sum(ms) / len(ms), [ms[int(q * (len(ms) - 1))] for q in (0.1, 0.5, 0.9)], wall
 
 
+def recorded_traffic(key):
+    """HBM bytes per launch from the PMC passes kept under profiles/ (collected with this kernel, not in this run), and
+    whether the kernel sources still are the ones that library was built from."""
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        ent = json.load(open(tpath)).get(key, {})
+        sys.path.insert(0, os.path.join(ROOT, "profiles", "tools"))
+        from update_traffic import kernel_source_fingerprint
+        return ent.get("hbm_bytes_per_launch"), ent.get("kernel_source_fingerprint") == kernel_source_fingerprint()
+    except Exception:
+        return None, None
+
+
 def bench_yamnet(args):
     """BASELINE.json configs[0]: YAMNet features (16 kHz, 400/160/512, 64 HTK mel, ln(x + 0.001)) on 64 clips of 10 s,
     and on the 512-clip shard of the stream server; the CPU line is the TensorFlow formulation of the same features
@@ -136,6 +149,7 @@ def bench_yamnet(args):
                    "ms_per_step": wall / args.steps * 1e3, "audio_hours_per_s": B * 10 / 3600.0 / (wall / args.steps),
                    "algorithmic_bytes_per_launch": alg, "achieved_GBps": alg / (kern_ms * 1e-3) / 1e9}
     big = rows[512]
+    traffic, traffic_current = recorded_traffic("flavour_yamnet")
     res = {"metric": "log-mel audio-hours/sec", "value": big["audio_hours_per_s"], "unit": "audio-hours/s", "n_gpus": 1,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": big["ms_per_step"], "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -143,7 +157,9 @@ def bench_yamnet(args):
                                   "is the 512-clip shard of the stream server, the 64-clip batch of configs[0] is in batches",
                       "batches": [rows[64], rows[512]], "pcm": "f32", "parallelism": "1 GPU"},
            "roofline": {"bound": "hbm", "kernel": "stft_mel_kernel<n_fft=512, magnitude, mel+log>", "achieved": big["achieved_GBps"],
-                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": big["achieved_GBps"] / HBM_PEAK_GBS, "traffic": None,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": big["achieved_GBps"] / HBM_PEAK_GBS, "traffic": traffic,
+                        "traffic_source": "profiles/hbm_traffic.json (rocprofv3 PMC passes of kbench -c yamnet, not this run)",
+                        "traffic_is_of_these_kernel_sources": traffic_current,
                         "algorithmic_bytes_per_launch": big["algorithmic_bytes_per_launch"], "kernel_ms": big["kernel_ms"]}}
     if not args.no_cpu_baseline:
         from oracle.cpu_baseline import YamnetCpuFrontend, time_cpu_frontend
@@ -577,19 +593,7 @@ def main():
 
     h2d = measure_h2d(x) if rank == 0 else None
 
-    # HBM bytes per launch from the PMC passes kept under profiles/ (collected with this command, not in this run), and
-    # whether the kernel sources still are the ones that library was built from
-    traffic, traffic_current = None, None
-    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            ent = json.load(open(tpath)).get("htsat_b256_fp32", {})
-            traffic = ent.get("hbm_bytes_per_launch")
-            sys.path.insert(0, os.path.join(ROOT, "profiles", "tools"))
-            from update_traffic import kernel_source_fingerprint
-            traffic_current = ent.get("kernel_source_fingerprint") == kernel_source_fingerprint()
-        except Exception:
-            traffic, traffic_current = None, None
+    traffic, traffic_current = recorded_traffic("htsat_b256_fp32")
 
     res = {
         "metric": "log-mel audio-hours/sec", "value": value, "unit": "audio-hours/s", "n_gpus": world,

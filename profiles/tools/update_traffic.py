@@ -31,7 +31,14 @@ def main():
                 "gfx950 correction for wide coalesced streaming reads",
         "source": "profiles/r03_stft_mel.json", "library": note,
         "kernel_source_fingerprint": kernel_source_fingerprint()}}
-    json.dump(out, open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:  # entries of the other flavours (profiles/tools/traffic_all.sh) stay
+        old = json.load(open(path))
+        old.update(out)
+        out = old
+    except Exception:
+        pass
+    json.dump(out, open(path, "w"), indent=1)
     print(json.dumps(out, indent=1))
 
 
