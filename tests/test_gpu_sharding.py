@@ -185,6 +185,37 @@ def test_decode_and_exchange_beyond_the_one_launch_limit():
         assert int(got[0, 0, 0]) > 100 and int(got[1, 0, 0]) == 0
 
 
+def test_serving_step_under_graph_capture():
+    """One rank's serving step (fused log-mel kernel of the detector features + one decode kernel with the event records)
+    captured in a HIP graph after one eager warm-up and replayed on new audio and new detector outputs: the entry points
+    are stream operations only (no allocation or synchronisation at call time beyond torch's graph-private pool), so the
+    replays equal the eager results bit for bit."""
+    import sed_amd
+    from sed_amd import decode as D
+    dev = _dev()
+    S, n = 24, 48000
+    fe = sed_amd.LogMelFrontend(sed_amd.FrontendConfig.yamnet(), layout="btm")
+    table = torch.tensor([k * 0.48 for k in range(43)], dtype=torch.float64, device=dev)
+    gen = torch.Generator(device=dev).manual_seed(5)
+    pcm = 0.1 * torch.randn((S, n), generator=gen, device=dev)
+    det = torch.rand((S, 41, 1), generator=gen, device=dev)
+    fe(pcm)
+    D.threshold_merge_records(det, 0.5, table, 0.6, "median3", 16, 0)             # warm-up: kernel attributes, plan upload
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        g_mel = fe(pcm)
+        g_rec = D.threshold_merge_records(det, 0.5, table, 0.6, "median3", 16, 0)
+    for seed in (11, 12, 13):
+        gen = torch.Generator(device=dev).manual_seed(seed)
+        pcm.copy_(0.1 * torch.randn((S, n), generator=gen, device=dev))
+        det.copy_(torch.rand((S, 41, 1), generator=gen, device=dev))
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(g_mel, fe(pcm))
+        assert torch.equal(g_rec, D.threshold_merge_records(det, 0.5, table, 0.6, "median3", 16, 0))
+
+
 def test_exchange_over_rccl_one_rank_group(rccl_group):
     """The function bench.py times (decode -> records -> all-gather), with the collective forced on a one-rank RCCL group."""
     import sed_amd
