@@ -133,6 +133,22 @@ def test_other_windows_of_the_torchlibrosa_surface():
         ref32 = of.power_to_db(of.power_spectrogram_ref32(x, n_fft, hop, win_length, window_full=wfull) @ melW)[:, None]
         _check(fused, gold, ref32, NEAR_DB)
         assert torch.max(torch.abs(torch.from_numpy(fused).to(dev) - lm(sp(xt)))).item() < 1e-4
+    # the other framing options with a window that is not Hann: no centring, zero padding, hops that are no multiple of 64
+    # samples, int16 samples
+    for center, pad_mode, hop in ((False, "reflect", 320), (True, "constant", 252), (False, "constant", 332)):
+        wfull = get_window("hamming", 1024, fftbins=True).astype(np.float64)
+        sp = sed_amd.Spectrogram(n_fft=1024, hop_length=hop, window="hamming", center=center, pad_mode=pad_mode).to(dev)
+        p = sp(xt)[:, 0].cpu().numpy().astype(np.float64)
+        gold_p = of.power_spectrogram_gold(x, 1024, hop, 1024, center=center, pad_mode=pad_mode, window_full=wfull)
+        assert p.shape == gold_p.shape, (center, pad_mode, hop)
+        assert np.max(np.abs(p - gold_p) / np.maximum(gold_p.max(axis=-1, keepdims=True), 1e-30)) < 2e-6, (center, pad_mode, hop)
+    cfg16 = sed_amd.FrontendConfig.htsat(pcm_kind=1, pcm_divisor=32767.0)
+    s16 = of.f32_to_pcm16(x)
+    fe16 = sed_amd.LogMelFrontend(cfg16, layout="btm", window=("kaiser", 6.0))
+    fe32 = sed_amd.LogMelFrontend(sed_amd.FrontendConfig.htsat(), layout="btm", window=("kaiser", 6.0))
+    got16 = fe16(torch.from_numpy(s16).to(dev))
+    want16 = fe32(torch.from_numpy(of.pcm16_to_f32(s16)).to(dev))
+    assert torch.equal(got16, want16)                                   # the int16 path converts as the reference does, then the same kernel
     # an array and a callable give what the name gives
     ham = get_window("hamming", 1024, fftbins=True)
     want = sed_amd.Spectrogram(n_fft=1024, hop_length=320, window="hamming")(xt)
@@ -140,6 +156,8 @@ def test_other_windows_of_the_torchlibrosa_surface():
     assert torch.equal(sed_amd.Spectrogram(n_fft=1024, hop_length=320, window=lambda n: get_window("hamming", n))(xt), want)
     with pytest.raises(ValueError):
         sed_amd.Spectrogram(n_fft=1024, hop_length=320, window=ham[:-1])
+    with pytest.raises(ValueError, match="multiple of 4"):               # frames start on 16-byte units of the staged span
+        sed_amd.Spectrogram(n_fft=1024, hop_length=250)(xt)
     # a state_dict saved with one window does not load into a module built with another
     a = sed_amd.Spectrogram(n_fft=1024, hop_length=320, window="hamming")
     b = sed_amd.Spectrogram(n_fft=1024, hop_length=320, window="hann")
