@@ -58,7 +58,7 @@ typedef struct sed_frontend_cfg {
   int32_t sample_rate;
   int32_t n_fft;            /* 512, 1024 or 2048                                                   */
   int32_t win_length;       /* <= n_fft; periodic Hann                                             */
-  int32_t hop;              /* a multiple of 4 samples (any hop with remove_dc / preemphasis: the Kaldi framing)    */
+  int32_t hop;              /* any; multiples of 4 samples take the aligned (faster) sample reads                  */
   int32_t center;           /* 1: pad n_fft/2 both sides with pad_mode; T = 1 + L/hop              */
   int32_t pad_mode;         /* SED_PAD_* (used when center)                                        */
   int32_t win_align;        /* SED_WIN_CENTER (librosa pad_center) or SED_WIN_LEFT (tf.signal.stft) */

@@ -237,6 +237,12 @@ struct SrcF32 {
   SED_HD v2 load2(int o) const { return ld2(p + o); }
   SED_HD v4 load4(int o) const { return ld4(p + o); }
 };
+// fp32 samples from a frame that starts on any sample (hops that are not a multiple of 4): 4-byte reads
+struct SrcF32U {
+  const float* p;
+  SED_HD v2 load2(int o) const { return v2{p[o], p[o + 1]}; }
+  SED_HD v4 load4(int o) const { return v4{p[o], p[o + 1], p[o + 2], p[o + 3]}; }
+};
 struct alignas(4) i16x2 {
   short x, y;
 };

@@ -726,7 +726,12 @@ stft_mel_kernel(const FrontParams p) {
           lane_load_samples_skewed<G, Mel::HOP, SKEW>(st, X + fi * (Mel::HOP + SKEW), l);
           lane_stage1<G, SrcF32, true>(st, SrcF32{nullptr}, winL, tw1L, l);
         } else {
-          lane_stage1<G>(st, SrcF32{X + fi * p.hop}, winL, tw1L, l);
+          // frames of a hop that is not a multiple of 4 samples start off the 8- / 16-byte units of the aligned reads:
+          // built for the run-time mel shapes only (every compiled-in flavour has such a hop)
+          bool aligned = true;
+          if constexpr (!Mel::kStatic) aligned = (p.hop & 3) == 0;  // wave-uniform
+          if (aligned) lane_stage1<G>(st, SrcF32{X + fi * p.hop}, winL, tw1L, l);
+          else lane_stage1<G, SrcF32U>(st, SrcF32U{X + fi * p.hop}, winL, tw1L, l);
         }
       }
       wave_phase_fence();
@@ -1216,7 +1221,6 @@ extern "C" int sed_plan_create(const sed_frontend_cfg* cfg, sed_plan** out) {
   if (cfg->hop < 1 || cfg->hop > cfg->n_fft) return SED_ERR_BAD_ARG;
   // frames are read from LDS 8 or 16 bytes at a time: the hop must keep them aligned, except with per-frame
   // conditioning, which reads sample by sample (Kaldi's 10 ms shift at 44.1 kHz is 441 samples)
-  if (cfg->hop % 4 != 0 && !(cfg->remove_dc || cfg->preemphasis > 0.0f)) return SED_ERR_BAD_ARG;
   if (cfg->n_mels < 1 || cfg->n_mels > 128 || cfg->sample_rate < 1) return SED_ERR_BAD_ARG;
   if (cfg->spectrum != SED_SPEC_MAGNITUDE && cfg->spectrum != SED_SPEC_POWER) return SED_ERR_BAD_ARG;
   if (cfg->center && cfg->pad_mode != SED_PAD_CONSTANT && cfg->pad_mode != SED_PAD_REFLECT) return SED_ERR_BAD_ARG;
@@ -1501,7 +1505,8 @@ static int launch_front(const sed_plan* pl, const FrontParams& p, int64_t B, hip
     const bool two = p.n_quads > 16;
     // (sets, steps of the first n_hi sets, steps of the others, n_hi, most positions per quad, two gather rounds)
     auto is = [&](int sets, int u, int ulo, int nhi, int maxpos, bool rounds2) {
-      return p.mel_sets == sets && p.mel_u == u && p.mel_ulo == ulo && p.mel_nhi == nhi && p.mel_maxpos == maxpos && two == rounds2;
+      return p.hop % 4 == 0 && p.mel_sets == sets && p.mel_u == u && p.mel_ulo == ulo && p.mel_nhi == nhi && p.mel_maxpos == maxpos &&
+             two == rounds2;  // (hops off the 16-byte grid run the general kernel)
     };
     if constexpr (G::NFFT == 1024 && !MAG && !PRE) {  // HTS-AT: Slaney 64 mel, 50..14000 Hz at 32 kHz
 #ifdef SED_EST_MEL_U  // timing experiments: a shorter chain per accumulator set than the plan's schedule has (results are then garbage)

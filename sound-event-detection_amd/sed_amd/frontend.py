@@ -128,10 +128,6 @@ class _Plan:
     def __init__(self, cfg: FrontendConfig, device: torch.device):
         self.cfg, self.device = cfg, device
         self.ptr = C.c_void_p()
-        if cfg.hop % 4 != 0 and not (cfg.remove_dc or cfg.preemphasis > 0.0):
-            # frames start on 16-byte units of the staged span (the reference's hops are 160, 320, 512, 1024); only the
-            # Kaldi framing, whose 10 ms hop at 44.1 kHz is 441 samples, has the sample-aligned path
-            raise ValueError(f"hop = {cfg.hop}: the hop must be a multiple of 4 samples")
         c = cfg.to_c()
         with torch.cuda.device(device):
             L.check(L.lib.sed_plan_create(C.byref(c), C.byref(self.ptr)), "sed_plan_create")

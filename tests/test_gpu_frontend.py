@@ -156,8 +156,26 @@ def test_other_windows_of_the_torchlibrosa_surface():
     assert torch.equal(sed_amd.Spectrogram(n_fft=1024, hop_length=320, window=lambda n: get_window("hamming", n))(xt), want)
     with pytest.raises(ValueError):
         sed_amd.Spectrogram(n_fft=1024, hop_length=320, window=ham[:-1])
-    with pytest.raises(ValueError, match="multiple of 4"):               # frames start on 16-byte units of the staged span
-        sed_amd.Spectrogram(n_fft=1024, hop_length=250)(xt)
+    # hops that are no multiple of 4 samples (10 ms at 44.1 kHz = 441): frames start off the 16-byte grid of the staged span
+    for n_fft, hop in ((1024, 441), (1024, 250), (512, 333), (2048, 441), (512, 161)):
+        sp = sed_amd.Spectrogram(n_fft=n_fft, hop_length=hop).to(dev)
+        p = sp(xt)[:, 0].cpu().numpy().astype(np.float64)
+        gold_p = of.power_spectrogram_gold(x, n_fft, hop)
+        assert p.shape == gold_p.shape, (n_fft, hop)
+        assert np.max(np.abs(p - gold_p) / np.maximum(gold_p.max(axis=-1, keepdims=True), 1e-30)) < 2e-6, (n_fft, hop)
+        lm = sed_amd.LogmelFilterBank(sr=32000, n_fft=n_fft, n_mels=64, fmin=50, fmax=14000, top_db=None).to(dev)
+        fused = sed_amd.LogMelFrontend.from_torchlibrosa(sp, lm)(xt)
+        assert torch.max(torch.abs(fused - lm(sp(xt)))).item() < 1e-4, (n_fft, hop)
+        melW = of.librosa_mel(32000, n_fft, 64, 50, 14000).T
+        gold = of.power_to_db(gold_p @ melW.astype(np.float64))[:, None]
+        ref32 = of.power_to_db(of.power_spectrogram_ref32(x, n_fft, hop) @ melW)[:, None]
+        _check(fused.cpu().numpy(), gold, ref32, NEAR_DB)
+    # the same audio as int16 through such a hop
+    cfgo = sed_amd.FrontendConfig.htsat(hop_size=441)
+    cfgo16 = sed_amd.FrontendConfig.htsat(hop_size=441, pcm_kind=1, pcm_divisor=32767.0)
+    a = sed_amd.LogMelFrontend(cfgo16, layout="btm")(torch.from_numpy(s16).to(dev))
+    b = sed_amd.LogMelFrontend(cfgo, layout="btm")(torch.from_numpy(of.pcm16_to_f32(s16)).to(dev))
+    assert torch.equal(a, b)
     # a state_dict saved with one window does not load into a module built with another
     a = sed_amd.Spectrogram(n_fft=1024, hop_length=320, window="hamming")
     b = sed_amd.Spectrogram(n_fft=1024, hop_length=320, window="hann")
