@@ -21,6 +21,12 @@ them on the reference's call sites:
   F5     librosa.feature.melspectrogram(power=2.0) + power_to_db(ref=np.max)
          call site src/utils/audio_to_spectrograms.py:30-44
 
+A second opinion, short of a pin: tests/test_oracle_vs_transformers.py holds the
+mel scales and filterbanks, the framing options, the dB conversion and every
+flavour's whole chain (the Kaldi filterbank of F6 below included) to
+transformers.audio_utils, an installed numpy restatement of the same libraries
+by other authors, to a few fp32 ulps.
+
 Two evaluation modes per flavour:
   * gold  : fp64 arithmetic on the fp32 tables the reference would hold
             (window, mel matrix) -- the yardstick for the 1e-3 tolerance.
