@@ -165,3 +165,21 @@ def test_windows():
     np.testing.assert_allclose(ofe.hann_periodic(1024), au.window_function(1024, "hann"), rtol=0, atol=1e-15)
     np.testing.assert_allclose(ofe.pad_center(ofe.hann_periodic(400), 512),
                                au.window_function(400, "hann", frame_length=512), rtol=0, atol=1e-15)
+
+
+def test_htsat_image_fold_and_framewise_upsampling_against_clap():
+    """reshape_wav2img (external/hts_audio_transformer/model/htsat.py:729-744) and interpolate (utils.py:158-172) against
+    transformers' CLAP audio encoder, a port of HTS-AT that states the same fold with another order of reshapes."""
+    import types
+    import torch
+    clap = pytest.importorskip("transformers.models.clap.modeling_clap")
+    rng = np.random.default_rng(7)
+    for T, spec, ratio in ((1001, 256, 4), (1024, 256, 4), (700, 512, 8)):
+        x = rng.standard_normal((2, 1, T, spec // ratio)).astype(np.float32)
+        enc = types.SimpleNamespace(spec_size=spec, freq_ratio=ratio)
+        theirs = clap.ClapAudioEncoder.reshape_mel2img(enc, torch.from_numpy(x)).numpy()
+        mine = ofe.htsat_reshape_wav2img(x, spec, ratio)
+        assert mine.shape == theirs.shape == (2, 1, spec, spec)
+        np.testing.assert_allclose(mine, theirs, rtol=0, atol=0 if T == spec * ratio else 4e-6)
+    h = rng.standard_normal((3, 32, 6)).astype(np.float32)
+    assert np.array_equal(ofe.htsat_interpolate(h, 32), clap.interpolate(torch.from_numpy(h), 32).numpy())
