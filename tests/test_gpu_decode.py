@@ -348,3 +348,35 @@ def test_framewise_interpolate_and_pad():
     one_hot[0, np.arange(128), lab] = 1.0
     full = sed_amd.interpolate(torch.from_numpy(one_hot).to(dev), 32)
     assert full.shape == (1, 4096, 6) and torch.equal(full[0, ::32], torch.from_numpy(one_hot[0]).to(dev))
+
+
+def test_decoded_events_scored_like_main():
+    """The chain of main.py for the single-stage CRNN: probabilities -> events (crnn.py:418-459) -> calculate_metrics
+    (main.py:29-48).  Probabilities that are 0.9 inside the true events and 0.1 elsewhere decode to the truth quantised to
+    frames, which every segment of 1 s and every event within the 0.25 s collar must score as correct; one clip with its
+    label swapped gives exactly one substitution."""
+    import sed_amd
+    from oracle import metrics as om
+    fps, T, N = 43.06640625, 862, 12
+    labels = {0: "car_horn", 1: "cough", 2: "dog_bark", 3: "siren", 4: "gun_shot"}           # crnn/utils.py:77-89
+    rng = np.random.default_rng(3)
+    probs = np.full((N, T, 5), 0.1, np.float32)
+    names, gt = [f"clip_{i:02d}.wav" for i in range(N)], {}
+    for i, name in enumerate(names):
+        c = int(rng.integers(5))
+        a = int(rng.integers(40, 400))
+        b = a + int(rng.integers(60, 300))
+        probs[i, a:b, c] = 0.9
+        gt[name] = [{"file": name, "event_onset": a / fps, "event_offset": b / fps,
+                     "event_label": labels[c if i else (c + 1) % 5]}]                         # clip 0: another label
+    pred = sed_amd.decode_probabilities(probs, names, labels, fps)
+    assert all(len(pred[n]) == 1 for n in names)
+    ev, seg = sed_amd.calculate_metrics(pred, gt, time_resolution=1.0, t_collar=0.25, verbose=False)
+    assert (ev.overall["Nref"], ev.overall["Ntp"], ev.overall["Nsubs"], ev.overall["Nfp"], ev.overall["Nfn"]) == (N, N - 1, 1, 0, 0)
+    assert seg.overall["Nfp"] == seg.overall["Nfn"] == seg.overall["S"] > 0 and seg.overall["D"] == seg.overall["I"] == 0
+    assert seg.overall["Ntp"] == seg.overall["Nref"] - seg.overall["S"]
+    oe, osg = om.EventBasedMetrics(sed_amd.decode.CLASSES, t_collar=0.25), om.SegmentBasedMetrics(sed_amd.decode.CLASSES, 1.0)
+    for n in names:
+        oe.evaluate(gt[n], pred[n]); osg.evaluate(gt[n], pred[n])
+    assert ev.results()["overall"] == oe.results_overall_metrics() and seg.results()["overall"] == osg.results_overall_metrics()
+    assert "Event based metrics (onset-offset)" in str(ev) and "Segment based metrics" in str(seg)
