@@ -67,7 +67,7 @@ typedef struct sed_frontend_cfg {
   int32_t spectrum;         /* SED_SPEC_*                                                          */
   int32_t mel_kind;         /* SED_MEL_*                                                           */
   int32_t n_mels;           /* 1..128                                                              */
-  float fmin, fmax;
+  double fmin, fmax;        /* band edges in Hz, fp64 as librosa / torchaudio take them: the triangle feet depend on every bit */
   int32_t log_kind;         /* SED_LOG_*                                                           */
   float amin, ref;          /* DB10: 10*log10(max(x, amin)) - 10*log10(max(amin, ref))             */
   float ln_offset;          /* LN: ln(x + ln_offset)                                               */
@@ -95,7 +95,7 @@ const char* sed_status_string(int status);
  * (external/audio_mamba/src/dataloader.py:133).  fp64 arithmetic, rounded once to fp32; SED_MEL_SLANEY follows librosa
  * operation for operation instead (rfftfreq bin frequencies, triangles rounded to fp32, then scaled by the fp64 Slaney
  * factor and rounded again, as its in-place `weights *= enorm` on an fp32 array does). */
-int sed_mel_filterbank(int32_t mel_kind, int32_t sample_rate, int32_t n_fft, int32_t n_mels, float fmin, float fmax,
+int sed_mel_filterbank(int32_t mel_kind, int32_t sample_rate, int32_t n_fft, int32_t n_mels, double fmin, double fmax,
                        float* melW_host);
 
 /* Periodic Hann of win_length inside n_fft samples (centred or left aligned), fp32 [n_fft]. */

@@ -22,9 +22,31 @@
     }                                                                           \
   } while (0)
 
+// Libraries up to version 0.2 take the band edges of the configuration as fp32 (they are fp64 since 0.3): builds of
+// both kinds can be timed in one call, each given the layout it was compiled for.
+struct sed_frontend_cfg_v02 {
+  int32_t sample_rate, n_fft, win_length, hop, center, pad_mode, win_align, tail_min_samples, tail_hop_samples, spectrum,
+      mel_kind, n_mels;
+  float fmin, fmax;
+  int32_t log_kind;
+  float amin, ref, ln_offset;
+  int32_t pcm_kind;
+  float pcm_divisor;
+  int32_t window_kind, remove_dc;
+  float preemphasis;
+};
+
+static sed_frontend_cfg_v02 to_v02(const sed_frontend_cfg& c) {
+  return sed_frontend_cfg_v02{c.sample_rate, c.n_fft, c.win_length, c.hop, c.center, c.pad_mode, c.win_align,
+                              c.tail_min_samples, c.tail_hop_samples, c.spectrum, c.mel_kind, c.n_mels, (float)c.fmin,
+                              (float)c.fmax, c.log_kind, c.amin, c.ref, c.ln_offset, c.pcm_kind, c.pcm_divisor,
+                              c.window_kind, c.remove_dc, c.preemphasis};
+}
+
 struct Lib {
   void* h;
-  int (*create)(const sed_frontend_cfg*, sed_plan**);
+  bool v02;
+  int (*create)(const void*, sed_plan**);
   void (*destroy)(sed_plan*);
   int64_t (*frames)(const sed_plan*, int64_t);
   int (*forward)(const sed_plan*, const void*, int64_t, int64_t, int64_t, float*, int64_t, void*);
@@ -35,6 +57,8 @@ static Lib open_lib(const char* path) {
   l.h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
   if (!l.h) { fprintf(stderr, "dlopen %s: %s\n", path, dlerror()); exit(2); }
   l.create = (decltype(l.create))dlsym(l.h, "sed_plan_create");
+  auto version = (const char* (*)())dlsym(l.h, "sed_version");
+  l.v02 = version && (!strncmp(version(), "sedhip 0.1", 10) || !strncmp(version(), "sedhip 0.2", 10));
   l.destroy = (decltype(l.destroy))dlsym(l.h, "sed_plan_destroy");
   l.frames = (decltype(l.frames))dlsym(l.h, "sed_plan_num_frames");
   l.forward = (decltype(l.forward))dlsym(l.h, "sed_logmel_forward");
@@ -107,7 +131,8 @@ int main(int argc, char** argv) {
   for (size_t li = 0; li < libs.size(); ++li) {
     Lib lib = open_lib(libs[li]);
     sed_plan* pl = nullptr;
-    int rc = lib.create(&c, &pl);
+    const sed_frontend_cfg_v02 c02 = to_v02(c);
+    int rc = lib.create(lib.v02 ? (const void*)&c02 : (const void*)&c, &pl);
     if (rc) { printf("%-40s plan_create failed %d\n", libs[li], rc); continue; }
     const int64_t T = lib.frames(pl, L);
     const size_t on = (size_t)B * T * c.n_mels;

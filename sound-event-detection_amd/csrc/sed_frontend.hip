@@ -1172,7 +1172,7 @@ static std::vector<float> build_mel(int mel_kind, int sr, int n_fft, int n_mels,
   return mel_slaney(sr, n_fft, n_mels, fmin, fmax);
 }
 
-extern "C" const char* sed_version(void) { return "sedhip 0.2.0 (gfx950)"; }
+extern "C" const char* sed_version(void) { return "sedhip 0.3.0 (gfx950)"; }
 
 extern "C" const char* sed_status_string(int status) {
   switch (status) {
@@ -1188,10 +1188,10 @@ extern "C" const char* sed_status_string(int status) {
   return "unknown status";
 }
 
-extern "C" int sed_mel_filterbank(int32_t mel_kind, int32_t sample_rate, int32_t n_fft, int32_t n_mels, float fmin,
-                                  float fmax, float* melW) {
-  if (!melW || sample_rate < 1 || n_fft < 2 || n_mels < 1 || fmin < 0.0f) return SED_ERR_BAD_ARG;
-  if (mel_kind == SED_MEL_KALDI ? !((fmax <= 0.0f ? fmax + 0.5f * sample_rate : fmax) > fmin) : !(fmax > fmin)) return SED_ERR_BAD_ARG;
+extern "C" int sed_mel_filterbank(int32_t mel_kind, int32_t sample_rate, int32_t n_fft, int32_t n_mels, double fmin,
+                                  double fmax, float* melW) {
+  if (!melW || sample_rate < 1 || n_fft < 2 || n_mels < 1 || !(fmin >= 0.0)) return SED_ERR_BAD_ARG;
+  if (mel_kind == SED_MEL_KALDI ? !((fmax <= 0.0 ? fmax + 0.5 * sample_rate : fmax) > fmin) : !(fmax > fmin)) return SED_ERR_BAD_ARG;
   const std::vector<float> w = build_mel(mel_kind, sample_rate, n_fft, n_mels, fmin, fmax);
   std::memcpy(melW, w.data(), w.size() * sizeof(float));
   return SED_OK;
@@ -1226,8 +1226,8 @@ extern "C" int sed_plan_create(const sed_frontend_cfg* cfg, sed_plan** out) {
   if (cfg->center && cfg->pad_mode != SED_PAD_CONSTANT && cfg->pad_mode != SED_PAD_REFLECT) return SED_ERR_BAD_ARG;
   if (cfg->pcm_kind == SED_PCM_I16 && !(cfg->pcm_divisor > 0.0f)) return SED_ERR_BAD_ARG;
   if (cfg->tail_min_samples > 0 && cfg->tail_hop_samples < 1) return SED_ERR_BAD_ARG;
-  if (cfg->fmin < 0.0f) return SED_ERR_BAD_ARG;
-  if (cfg->mel_kind == SED_MEL_KALDI ? !((cfg->fmax <= 0.0f ? cfg->fmax + 0.5f * cfg->sample_rate : cfg->fmax) > cfg->fmin)
+  if (!(cfg->fmin >= 0.0)) return SED_ERR_BAD_ARG;
+  if (cfg->mel_kind == SED_MEL_KALDI ? !((cfg->fmax <= 0.0 ? cfg->fmax + 0.5 * cfg->sample_rate : cfg->fmax) > cfg->fmin)
                                      : !(cfg->fmax > cfg->fmin)) return SED_ERR_BAD_ARG;
   if (cfg->window_kind != SED_WINDOW_HANN_PERIODIC && cfg->window_kind != SED_WINDOW_HANN_SYMMETRIC) return SED_ERR_BAD_ARG;
   if (cfg->preemphasis < 0.0f || cfg->preemphasis >= 1.0f || (cfg->remove_dc != 0 && cfg->remove_dc != 1)) return SED_ERR_BAD_ARG;

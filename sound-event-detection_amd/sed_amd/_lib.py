@@ -37,7 +37,7 @@ class FrontendCfg(C.Structure):
         ("center", C.c_int32), ("pad_mode", C.c_int32), ("win_align", C.c_int32),
         ("tail_min_samples", C.c_int32), ("tail_hop_samples", C.c_int32),
         ("spectrum", C.c_int32), ("mel_kind", C.c_int32), ("n_mels", C.c_int32),
-        ("fmin", C.c_float), ("fmax", C.c_float),
+        ("fmin", C.c_double), ("fmax", C.c_double),
         ("log_kind", C.c_int32), ("amin", C.c_float), ("ref", C.c_float), ("ln_offset", C.c_float),
         ("pcm_kind", C.c_int32), ("pcm_divisor", C.c_float),
         ("window_kind", C.c_int32), ("remove_dc", C.c_int32), ("preemphasis", C.c_float),
@@ -50,7 +50,7 @@ _vp, _i32, _i64, _f32, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_d
 SIGNATURES = {
     "sed_version": (C.c_char_p, []),
     "sed_status_string": (C.c_char_p, [C.c_int]),
-    "sed_mel_filterbank": (C.c_int, [_i32, _i32, _i32, _i32, _f32, _f32, _vp]),
+    "sed_mel_filterbank": (C.c_int, [_i32, _i32, _i32, _i32, _f64, _f64, _vp]),
     "sed_hann_window": (C.c_int, [_i32, _i32, _i32, _vp]),
     "sed_window": (C.c_int, [_i32, _i32, _i32, _i32, _vp]),
     "sed_plan_create": (C.c_int, [C.POINTER(FrontendCfg), C.POINTER(_vp)]),

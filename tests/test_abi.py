@@ -43,7 +43,7 @@ def test_cfg_struct_matches_header():
             continue
         ty, names = decl.split(None, 1)
         fields += [(n.strip(), ty) for n in names.split(",")]
-    want = [(n, {"int32_t": ctypes.c_int32, "float": ctypes.c_float}[t]) for n, t in fields]
+    want = [(n, {"int32_t": ctypes.c_int32, "float": ctypes.c_float, "double": ctypes.c_double}[t]) for n, t in fields]
     assert [(n, t) for n, t in _lib.FrontendCfg._fields_] == want
 
 
@@ -56,7 +56,25 @@ def test_host_tables_match_oracle():
                      (sed_amd.FrontendConfig.yamnet(), of.tf_linear_to_mel_weight_matrix())):
         got = sed_amd.mel_filterbank(cfg).numpy()
         assert got.shape == ref.shape
-        assert np.max(np.abs(got - ref)) <= 1e-9
+        assert np.array_equal(got, ref)
+    # Band edges cross the C ABI as fp64: the feet of the triangles depend on every bit of them (an edge rounded to fp32
+    # moves a weight next to a foot by 5e-4 of its value), and callers pass whatever fp64 the model was configured with.
+    import dataclasses
+    rng = np.random.default_rng(0)
+    for case in range(60):
+        sr = int(rng.choice([8000, 16000, 22050, 32000, 44100, 48000]))
+        n_fft = int(rng.choice([512, 1024, 2048]))
+        M = int(rng.integers(1, 129))
+        fmin = float(rng.uniform(0, 400))
+        fmax = float(rng.uniform(max(fmin + 500, 0.2 * sr), 0.5 * sr))
+        cfg = sed_amd.FrontendConfig.htsat(sample_rate=sr, window_size=n_fft, hop_size=n_fft // 4, mel_bins=M, fmin=fmin, fmax=fmax)
+        assert np.array_equal(sed_amd.mel_filterbank(cfg).numpy(), of.librosa_mel(sr, n_fft, M, fmin, fmax).T), (sr, n_fft, M, fmin, fmax)
+        if case % 3 == 0:
+            M2, lo, hi = int(rng.integers(8, 129)), float(rng.uniform(20, 300)), float(rng.uniform(3000, 8000))
+            cfg = dataclasses.replace(sed_amd.FrontendConfig.yamnet(), n_mels=M2, fmin=lo, fmax=hi)
+            assert np.array_equal(sed_amd.mel_filterbank(cfg).numpy(), of.tf_linear_to_mel_weight_matrix(M2, 257, 16000, lo, hi))
+            kc = sed_amd.FrontendConfig.kaldi_fbank(16000.0, M2, low_freq=lo)
+            assert np.array_equal(sed_amd.mel_filterbank(kc).numpy(), of.kaldi_mel_banks(M2, 512, 16000.0, lo, 0.0).T.astype(np.float32))
     kcfg = sed_amd.FrontendConfig.kaldi_fbank(16000.0, 128)
     assert (kcfg.n_fft, kcfg.win_length, kcfg.hop) == (512, 400, 160)
     got = sed_amd.mel_filterbank(kcfg).numpy()
