@@ -304,8 +304,10 @@ int sed_framewise_expand(const float* x, int64_t B, int64_t T, int64_t C, int32_
  * (librosa.load(file_path, sr=16000), src/models/yamnet_train.py:46 and src/models/single_stage_yamnet_frame.py:25-27;
  * librosa.resample(track, ofs, rfs), external/hts_audio_transformer/utils.py:211), i.e. soxr_hq, whose filter lives in
  * libsoxr: this entry point replaces those calls only when they are given res_type='polyphase'.
- * Supported: target_sr/g <= 512 and at most 128 filter coefficients per phase (orig_sr/target_sr up to about 6),
- * else SED_ERR_BAD_ARG. */
+ * Any pair of rates with max(up, down) <= 2^20 (up = target_sr/g, down = orig_sr/g): pairs with up <= 512 and at most 128
+ * filter coefficients per phase (orig_sr/target_sr up to about 6), or up <= 1024 and at most 64 of them, run the tiled
+ * LDS kernels (every pair of the usual audio rates from 8 to 48 kHz but 11.025 -> 32 kHz), the others a general kernel with the same bits at a fraction of the
+ * speed. */
 typedef struct sed_resampler sed_resampler;
 int sed_resampler_create(int32_t orig_sr, int32_t target_sr, sed_resampler** out);
 void sed_resampler_destroy(sed_resampler* r);

@@ -311,6 +311,35 @@ __global__ void __launch_bounds__(MAXT) resample_dma_kernel(const ResampleParams
   }
 }
 
+// Any rate pair: one thread per output sample, coefficients ([up][taps], `taps` the row length) and samples read from
+// global memory; neighbouring threads re-read both, so they come from the caches.  For the pairs the kernels above do not
+// hold (more than 512 phases, more than 128 coefficients per phase) and for PCM pointers the LDS-DMA kernel cannot take.
+// The same order of operations, hence the same bits; several times slower per sample.
+template <typename T>
+__global__ void __launch_bounds__(256) resample_any_kernel(const ResampleParams p, int taps) {
+  const int64_t total = p.B * (int64_t)p.n_out;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t b = i / p.n_out;
+    const int m = (int)(i - b * p.n_out);
+    const int64_t tt = ((int64_t)m + p.n_pre_remove) * p.down;
+    const int phase = (int)(tt % p.up);
+    const int64_t q = tt / p.up;  // newest input sample of output m
+    const T* src = (const T*)p.pcm + b * p.pcm_stride;
+    const float* c = p.table + (int64_t)phase * taps;
+    float acc = 0.0f;
+    for (int j = taps - 1; j >= 0; --j) {  // oldest input first, as scipy accumulates
+      const int64_t k = q - j;
+      float v = 0.0f;
+      if (k >= 0 && k < p.L) {
+        if constexpr (std::is_same<T, float>::value) v = src[k];
+        else v = (float)src[k] / p.div;
+      }
+      acc = __fadd_rn(acc, __fmul_rn(v, c[j]));
+    }
+    p.out[b * p.out_stride + m] = acc;
+  }
+}
+
 static double bessel_i0(double x) {
   const double q = 0.25 * x * x;
   double term = 1.0, total = 1.0;
@@ -341,6 +370,7 @@ struct sed_resampler {
   int32_t dma_groups = 0, dma_stage_count = 0, dma_rounds = 0;  // LDS-DMA variant (fp32 input), 0 groups: not available
   std::vector<int32_t> assign;    // [threads] output of a group owned by each thread
   int32_t* d_assign = nullptr;
+  bool any = false;               // served by resample_any_kernel alone (d_table is [up][taps] then)
   bool b64 = false;               // the LDS-DMA variant reads sample pairs from even offsets (8-byte LDS reads)
   std::vector<int32_t> assign64;  // its thread -> output table
   int32_t* d_assign64 = nullptr;
@@ -360,6 +390,10 @@ extern "C" int sed_resampler_create(int32_t orig_sr, int32_t target_sr, sed_resa
   if (!r) return SED_ERR_BAD_ARG;
   r->up = up;
   r->down = down;
+  if (std::max(up, down) > (1 << 20)) {  // a filter of 20 * max(up, down) + 1 coefficients: rates without a common factor to speak of
+    delete r;
+    return SED_ERR_BAD_ARG;
+  }
   if (up == 1 && down == 1) {
     r->taps = 1;
     r->n_pre_remove = 0;
@@ -394,57 +428,61 @@ extern "C" int sed_resampler_create(int32_t orig_sr, int32_t target_sr, sed_resa
   for (int sz : kSizes)
     if (r->tp == 0 && r->taps <= sz) r->tp = sz;
   const int max_threads = 512;
-  if (r->tp == 0 || up > max_threads) {  // a thread per phase, a register per coefficient
-    delete r;
-    return SED_ERR_BAD_ARG;
-  }
-  // P periods of `up` outputs per group: about 256 threads; R groups per tile, as many of {4, 2, 1} as the staging
-  // registers and 64 KB of LDS allow
-  r->periods = std::max(1, std::min(max_threads / up, (256 + up - 1) / up));
-  {
-    // Workgroups whose wavefront count is not a multiple of four leave the CU half empty: with 320 threads (5 wavefronts) of
-    // 110 registers a CU held 7 wavefronts on average instead of the 15 its registers and LDS allow, with 480 threads (8
-    // wavefronts) it holds 14 (SQ_WAVE_CYCLES against GRBM_GUI_ACTIVE) -- as if the wavefronts of every workgroup went to the
-    // four SIMDs in turn starting from the first, so that two 5-wavefront workgroups fill the first SIMD's registers.  Prefer, among
-    // the period counts of at least 256 threads, the one whose wavefronts spread most evenly over the SIMDs, and one
-    // whose group advances by an even number of input samples (8-byte LDS reads, see resample_dma_kernel).  Workgroups of
-    // more than 512 threads exist for the LDS-DMA kernel only (phases of at most 64 coefficients, whole half wavefronts,
-    // its buffers within 64 KB).
-    auto dma_fits = [&](int P) {
-      const int64_t threads = (int64_t)up * P, qstep = (int64_t)P * down;
-      if (threads % 32 != 0) return false;
-      const int64_t count = ((threads - 1 + r->n_pre_remove) * down) / up - ((int64_t)r->n_pre_remove * down) / up + r->tp + 1;
-      const int64_t rounds = (count + threads - 1) / threads;
-      (void)qstep;
-      return (2 * rounds * threads + 2 * threads) * 4 <= 64 * 1024;  // one group per tile at least
-    };
-    double best = 1e30;
-    const int first = r->periods;
-    for (int P = first; P >= 1 && (int64_t)up * P <= 1024; ++P) {
-      if (up * P > max_threads && !(r->tp <= 64 && dma_fits(P))) continue;
-      const int waves = (up * P + 63) / 64;
-      const double score = (double)((waves + 3) / 4) / (waves / 4.0)             // most loaded SIMD / average
-                           - (((int64_t)P * down) % 2 == 0 ? 0.2 : 0.0) + 1e-3 * P;
-      if (score < best - 1e-9) { best = score; r->periods = P; }
+  // the tiled kernels: a thread per phase, a register per coefficient; more than 512 phases in the LDS-DMA kernel only,
+  // whose workgroups of up to 1024 threads are built for phases of at most 64 coefficients
+  r->any = r->tp == 0 || up > 1024 || (up > max_threads && r->tp > 64);
+  int span1 = 0;
+  if (!r->any) {
+    // P periods of `up` outputs per group: about 256 threads; R groups per tile, as many of {4, 2, 1} as the staging
+    // registers and 64 KB of LDS allow
+    r->periods = std::max(1, std::min(max_threads / up, (256 + up - 1) / up));
+    {
+      // Workgroups whose wavefront count is not a multiple of four leave the CU half empty: with 320 threads (5 wavefronts) of
+      // 110 registers a CU held 7 wavefronts on average instead of the 15 its registers and LDS allow, with 480 threads (8
+      // wavefronts) it holds 14 (SQ_WAVE_CYCLES against GRBM_GUI_ACTIVE) -- as if the wavefronts of every workgroup went to the
+      // four SIMDs in turn starting from the first, so that two 5-wavefront workgroups fill the first SIMD's registers.  Prefer, among
+      // the period counts of at least 256 threads, the one whose wavefronts spread most evenly over the SIMDs, and one
+      // whose group advances by an even number of input samples (8-byte LDS reads, see resample_dma_kernel).  Workgroups of
+      // more than 512 threads exist for the LDS-DMA kernel only (phases of at most 64 coefficients, whole half wavefronts,
+      // its buffers within 64 KB).
+      auto dma_fits = [&](int P) {
+        const int64_t threads = (int64_t)up * P, qstep = (int64_t)P * down;
+        if (threads % 32 != 0) return false;
+        const int64_t count = ((threads - 1 + r->n_pre_remove) * down) / up - ((int64_t)r->n_pre_remove * down) / up + r->tp + 1;
+        const int64_t rounds = (count + threads - 1) / threads;
+        (void)qstep;
+        return (2 * rounds * threads + 2 * threads) * 4 <= 64 * 1024;  // one group per tile at least
+      };
+      double best = 1e30;
+      const int first = r->periods;
+      for (int P = first; P >= 1 && (int64_t)up * P <= 1024; ++P) {
+        if (up * P > max_threads && !(r->tp <= 64 && dma_fits(P))) continue;
+        const int waves = (up * P + 63) / 64;
+        const double score = (double)((waves + 3) / 4) / (waves / 4.0)             // most loaded SIMD / average
+                             - (((int64_t)P * down) % 2 == 0 ? 0.2 : 0.0) + 1e-3 * P;
+        if (score < best - 1e-9) { best = score; r->periods = P; }
+      }
     }
-  }
-  r->threads = up * r->periods;
-  r->q0 = (int32_t)(((int64_t)r->n_pre_remove * down) / up);
-  r->qstep = r->periods * down;
-  const int span1 = (int)((((int64_t)r->threads - 1 + r->n_pre_remove) * down) / up) - r->q0 + r->tp;
-  r->groups = 0;
-  for (int R : {8, 4, 2, 1}) {
-    const int64_t count = (int64_t)(R - 1) * r->qstep + span1;
-    if (r->groups == 0 && count <= (int64_t)stage_regs(R) * r->threads && (count + (int64_t)R * r->threads) * 4 <= 64 * 1024) {
-      r->groups = R;
-      r->stage_count = (int32_t)count;
+    r->threads = up * r->periods;
+    r->q0 = (int32_t)(((int64_t)r->n_pre_remove * down) / up);
+    r->qstep = r->periods * down;
+    span1 = (int)((((int64_t)r->threads - 1 + r->n_pre_remove) * down) / up) - r->q0 + r->tp;
+    r->groups = 0;
+    for (int R : {8, 4, 2, 1}) {
+      const int64_t count = (int64_t)(R - 1) * r->qstep + span1;
+      if (r->groups == 0 && count <= (int64_t)stage_regs(R) * r->threads && (count + (int64_t)R * r->threads) * 4 <= 64 * 1024) {
+        r->groups = R;
+        r->stage_count = (int32_t)count;
+      }
     }
+    if (r->groups == 0 && r->threads <= max_threads) r->any = true;
   }
-  if (r->groups == 0 && r->threads <= max_threads) {
-    delete r;
-    return SED_ERR_BAD_ARG;
+  if (r->any) {
+    r->tp = r->taps;
+    r->groups = r->dma_groups = 0;
+    r->threads = 256;
   }
-  if (r->threads % 32 == 0)  // (a last wavefront with 32 threads moves 32 samples per round: the rounds stay contiguous)
+  if (!r->any && r->threads % 32 == 0)  // (a last wavefront with 32 threads moves 32 samples per round: the rounds stay contiguous)
     for (int R : {4, 2, 1}) {  // two span buffers and two output buffers in at most 64 KB: two workgroups per CU
       const int64_t count = (int64_t)(R - 1) * r->qstep + span1;
       const int64_t rounds = (count + r->threads - 1) / r->threads;
@@ -485,7 +523,7 @@ extern "C" int sed_resampler_create(int32_t orig_sr, int32_t target_sr, sed_resa
       nb = (nb + 1) % 32;
     }
   }
-  {
+  if (!r->any) {
     // thread -> output assignment of a group: every wavefront gets outputs whose first LDS read falls into 64 different
     // banks (lane = bank; lanes i and i + 32 then also differ modulo 32), as far as the residues allow; later taps and
     // groups shift every lane by the same amount, so the property holds for all reads.
@@ -518,8 +556,8 @@ extern "C" int sed_resampler_create(int32_t orig_sr, int32_t target_sr, sed_resa
     for (int j = 0; j < r->taps; ++j) padded[(size_t)ph * r->tp + j] = r->table_host[(size_t)ph * r->taps + j];
   if (!rc) rc = rs_status(hipMalloc((void**)&r->d_table, padded.size() * sizeof(float)));
   if (!rc) rc = rs_status(hipMemcpy(r->d_table, padded.data(), padded.size() * sizeof(float), hipMemcpyHostToDevice));
-  if (!rc) rc = rs_status(hipMalloc((void**)&r->d_assign, r->assign.size() * sizeof(int32_t)));
-  if (!rc) rc = rs_status(hipMemcpy(r->d_assign, r->assign.data(), r->assign.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (!rc && !r->any) rc = rs_status(hipMalloc((void**)&r->d_assign, r->assign.size() * sizeof(int32_t)));
+  if (!rc && !r->any) rc = rs_status(hipMemcpy(r->d_assign, r->assign.data(), r->assign.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   if (!rc && r->b64) {
     rc = rs_status(hipMalloc((void**)&r->d_assign64, r->assign64.size() * sizeof(int32_t)));
     if (!rc) rc = rs_status(hipMemcpy(r->d_assign64, r->assign64.data(), r->assign64.size() * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -646,8 +684,10 @@ extern "C" int sed_resampler_forward(const sed_resampler* r, const void* pcm, in
   static const bool no_dma = getenv("SED_RS_NO_DMA") != nullptr, no_dma16 = getenv("SED_RS_NO_DMA16") != nullptr;
   dma = dma && !no_dma && (pcm_kind == SED_PCM_F32 || !no_dma16);
 #endif
-  if (!dma && r->threads > 512) return SED_ERR_BAD_ARG;  // (a PCM pointer that is not a multiple of its sample size)
-  const int threads = r->threads, R = dma ? r->dma_groups : r->groups;
+  // the general kernel: rate pairs the tiled kernels do not hold, and a workgroup of more than 512 threads whose PCM
+  // pointer is not a multiple of its sample size (such a workgroup exists for the LDS-DMA kernel only)
+  const bool any = r->any || (!dma && r->threads > 512);
+  const int threads = r->threads, R = any ? 1 : dma ? r->dma_groups : r->groups;
   ResampleParams p;
   p.pcm = pcm;
   p.out = out;
@@ -657,6 +697,17 @@ extern "C" int sed_resampler_forward(const sed_resampler* r, const void* pcm, in
   p.pcm_stride = pcm_stride;
   p.out_stride = out_stride;
   p.n_out = (int32_t)n_out;
+  if (any) {
+    p.up = r->up;
+    p.down = r->down;
+    p.n_pre_remove = r->n_pre_remove;
+    p.div = pcm_kind == SED_PCM_I16 ? pcm_divisor : 1.0f;
+    const int64_t want = (B * n_out + 255) / 256;
+    const int blocks = (int)std::min<int64_t>(want, (int64_t)r->num_cus * 64);
+    if (pcm_kind == SED_PCM_F32) hipLaunchKernelGGL(resample_any_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, r->tp);
+    else hipLaunchKernelGGL(resample_any_kernel<int16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, r->tp);
+    return rs_status(hipGetLastError());
+  }
   p.tiles = (int32_t)((n_out + (int64_t)R * threads - 1) / ((int64_t)R * threads));
   if (B * p.tiles > INT32_MAX / 2) return SED_ERR_BAD_ARG;
   p.up = r->up;

@@ -34,6 +34,27 @@ def test_bits_of_the_restatement(orig, target):
         assert got.shape == want.shape and np.array_equal(got, want), n
 
 
+@pytest.mark.parametrize("orig,target", ((192000, 8000), (96000, 12000), (22050, 32000), (11025, 48000), (37000, 6000)))
+def test_pairs_outside_the_tiled_kernels(orig, target):
+    """More than 512 phases (22.05 -> 32 kHz is 640 : 441) or more than 128 coefficients per phase (a ratio above about
+    6): the general kernel, one thread per output sample, same bits."""
+    import sed_amd
+    dev = _dev()
+    rng = np.random.default_rng(orig + target)
+    rs = sed_amd.Resampler(orig, target)
+    plan = R.plan(orig, target)
+    assert (rs.up, rs.down, rs.taps, rs.n_pre_remove) == (plan["up"], plan["down"], plan["taps"], plan["n_pre_remove"])
+    assert np.array_equal(rs.filter_table(), plan["table"])
+    for n in (1, 3, 999, 50001):
+        x = (rng.standard_normal((2, n)) * 0.3).astype(np.float32)
+        got = rs(torch.from_numpy(x).to(dev)).cpu().numpy()
+        want = R.resample_poly_f32(x, orig, target)
+        assert got.shape == want.shape and np.array_equal(got, want), n
+    s = rng.integers(-32768, 32768, size=(2, 20011), dtype=np.int16)
+    got = sed_amd.resample(torch.from_numpy(s).to(dev), orig_sr=orig, target_sr=target, pcm_divisor=32768.0).cpu().numpy()
+    assert np.array_equal(got, R.librosa_resample_polyphase(s.astype(np.float32) / np.float32(32768.0), orig, target))
+
+
 def test_librosa_signature_int16_and_errors():
     import sed_amd
     dev = _dev()
@@ -59,7 +80,7 @@ def test_librosa_signature_int16_and_errors():
     with pytest.raises(ValueError, match="polyphase"):
         sed_amd.resample(x, orig_sr=44100, target_sr=16000, res_type="soxr_hq")
     with pytest.raises(ValueError):
-        sed_amd.Resampler(192000, 8000)                                       # 481 coefficients per phase
+        sed_amd.Resampler(3000001, 2)                                         # a filter of 60 million coefficients
     assert sed_amd.Resampler(44100, 16000)(torch.zeros(2, 0, device=dev)).shape == (2, 0)
 
 
