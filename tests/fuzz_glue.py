@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Random sweep of the HTS-AT glue kernels and the event cut against their restatements (run by name on a GPU box; not
+collected by pytest):   python3 tests/fuzz_glue.py [cases] [seed]
+  * reshape_wav2img / repeat_wat2img (htsat.py:729-760): random batch, frames, image size and frequency ratio,
+  * interpolate + pad_framewise_output (utils.py:158-192): random shapes, identical values,
+  * cut_events (src/utils/cut_audio.py:13-53): random events, caps and sample types against numpy slicing, identical values.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "sound-event-detection_amd"))
+
+from oracle import frontend as of  # noqa: E402
+import sed_amd  # noqa: E402
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(seed)
+    bad = 0
+    for case in range(cases):
+        kind = case % 3
+        desc = dict(case=case)
+        try:
+            if kind == 0:
+                ratio = int(rng.choice([1, 2, 4, 8]))
+                spec = ratio * int(rng.choice([1, 2, 4, 8, 16, 32, 64]))
+                F, target_T = spec // ratio, spec * ratio
+                lo = min(max(2, target_T // 8), target_T)
+                T = int(rng.integers(lo, target_T + 1)) if rng.random() < 0.8 else target_T
+                B = int(rng.integers(1, 5))
+                desc = dict(case=case, kind="wav2img", B=B, T=T, F=F, spec=spec, ratio=ratio)
+                x = (rng.standard_normal((B, 1, T, F)) * 20 - 40).astype(np.float32)
+                xd = torch.from_numpy(x).to(dev)
+                got = sed_amd.reshape_wav2img(xd, spec, ratio).cpu().numpy()
+                want = of.htsat_reshape_wav2img(x, spec, ratio)
+                assert got.shape == want.shape
+                assert np.max(np.abs(got - want)) <= 2e-6 * np.max(np.abs(x)), f"wav2img {np.max(np.abs(got - want)):.3e}"
+                if T == target_T:
+                    assert np.array_equal(got, want), "fold without interpolation"
+                if ratio == 4 and spec <= target_T:       # the reference tiles the crop four times (htsat.py:758)
+                    pos = int(rng.integers(0, target_T - spec + 1))
+                    g2 = sed_amd.repeat_wat2img(xd, pos, spec, ratio).cpu().numpy()
+                    w2 = of.htsat_repeat_wat2img(x, pos, spec, ratio)
+                    assert g2.shape == w2.shape and np.max(np.abs(g2 - w2)) <= 2e-6 * np.max(np.abs(x)), "repeat_wat2img"
+            elif kind == 1:
+                B, T, C = int(rng.integers(1, 70)), int(rng.integers(1, 200)), int(rng.choice([1, 5, 6, 7, 64, 527]))
+                ratio = int(rng.choice([1, 2, 8, 32, 33]))
+                frames = T * ratio + int(rng.integers(0, 3 * ratio))
+                desc = dict(case=case, kind="framewise", B=B, T=T, C=C, ratio=ratio, frames=frames)
+                x = rng.random((B, T, C), dtype=np.float32)
+                xd = torch.from_numpy(x).to(dev)
+                want = of.htsat_pad_framewise_output(of.htsat_interpolate(x, ratio), frames)
+                assert np.array_equal(sed_amd.interpolate_and_pad(xd, ratio, frames).cpu().numpy(), want), "interpolate_and_pad"
+                assert np.array_equal(sed_amd.interpolate(xd, ratio).cpu().numpy(), of.htsat_interpolate(x, ratio)), "interpolate"
+            else:
+                S, n, sr = int(rng.integers(1, 6)), int(rng.integers(2000, 60000)), int(rng.choice([8000, 16000, 32000, 44100]))
+                i16 = bool(rng.random() < 0.4)
+                E = int(rng.integers(1, 30))
+                desc = dict(case=case, kind="cut", S=S, n=n, sr=sr, i16=i16, E=E)
+                pcm = rng.integers(-32768, 32768, size=(S, n), dtype=np.int16) if i16 else (rng.standard_normal((S, n)) * 0.3).astype(np.float32)
+                events = []
+                for _ in range(E):
+                    a = float(rng.uniform(0, n / sr))
+                    b = a + float(rng.uniform(0.0, 1.5))               # may run past the end of the recording
+                    events.append((int(rng.integers(S)), a, b))
+                cap = int(rng.integers(1, n + 100)) if rng.random() < 0.7 else None
+                kw = dict(pcm_divisor=32768.0) if i16 else {}
+                clips, lengths = sed_amd.cut_events(torch.from_numpy(pcm).to(dev), sr, events, cap, **kw)[:2]
+                clips, lengths = clips.cpu().numpy(), lengths.cpu().numpy()
+                src = pcm.astype(np.float32) / np.float32(32768.0) if i16 else pcm
+                for e, (s, a, b) in enumerate(events):
+                    full = src[s, int(a * sr):int(b * sr)]
+                    assert lengths[e] == len(full), f"length of event {e}: {lengths[e]} against {len(full)}"
+                    piece = full[:clips.shape[1]]                       # longer slices are truncated to the clip length
+                    assert np.array_equal(clips[e, :len(piece)], piece) and not clips[e, len(piece):].any(), f"event {e}"
+            print(f"ok   {desc}", flush=True)
+        except Exception as ex:  # noqa: BLE001
+            bad += 1
+            import traceback
+            print(f"FAIL {desc}: {type(ex).__name__}: {ex}\n{traceback.format_exc(limit=3)}", flush=True)
+    print(f"{cases - bad} of {cases} cases passed")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
