@@ -8,9 +8,11 @@ magnitude or power, mel count and band edges, batch, length and sample type, and
   * Spectrogram against the fp64 transform (relative to the frame's largest bin),
   * LogmelFilterBank(Spectrogram) and the fused module against each other and against the fp64 log-mel at the bar of
     tests/test_gpu_frontend.py,
-  * int16 input against the same samples as fp32 (bit for bit),
   * the segment mode (events read out of resident recordings) against cut + front-end (bit for bit),
-  * Kaldi filterbanks with random frame length / shift / mel count against the oracle.
+  * Kaldi filterbanks with random frame length / shift / mel count against the oracle,
+  * every eighth case: the functional entry points (extract_mbe, get_mel_spec_db, yamnet_log_mel) with arguments and
+    lengths the reference does not use, magnitude spectrograms, the whole-tensor top_db, int16 input against the same
+    samples as fp32 and a strided batch against a contiguous one (both bit for bit).
 Prints one line per case and a summary; exits 1 on the first failure with the case's parameters.
 """
 import os
@@ -129,6 +131,72 @@ def one_case(rng, case, dev):
         return False
 
 
+def functions_case(rng, case, dev):
+    """The functional entry points with arguments the reference does not use: extract_mbe and get_mel_spec_db with other
+    n_fft / hop / mel counts and lengths, YAMNet features of arbitrary lengths (tail padding), magnitude spectrograms, the
+    whole-tensor top_db of LogmelFilterBank, int16 input against the same samples as fp32."""
+    n_fft = int(rng.choice([512, 1024, 2048]))
+    sr = int(rng.choice([16000, 22050, 32000, 44100]))
+    hop = int(rng.integers(32, n_fft + 1))
+    n_mels = int(rng.integers(4, 129))
+    n = int(rng.integers(n_fft, sr))
+    B = int(rng.integers(1, 4))
+    desc = dict(case=case, kind="functions", n_fft=n_fft, sr=sr, hop=hop, n_mels=n_mels, n=n, B=B)
+    try:
+        y = of.synth_batch(B, n, sr, first=5000 + case)
+        ln_span = NEAR_DB / 20.0 * np.log(10.0)
+        mbe = sed_amd.extract_mbe(y, sr, n_fft, n_mels, hop)
+        check(np.swapaxes(mbe, -1, -2), np.swapaxes(of.crnn_extract_mbe(y, sr, n_fft, n_mels, hop, mode="gold"), -1, -2),
+              np.swapaxes(of.crnn_extract_mbe(y, sr, n_fft, n_mels, hop, mode="ref32"), -1, -2), ln_span, per_unit=2.0)
+        top_db = float(rng.choice([80.0, 60.0, 120.0]))
+        db = sed_amd.get_mel_spec_db(y, sr, n_fft, hop, n_mels, top_db)
+        want = of.librosa_db_mel(y, sr, n_fft, hop, n_mels, mode="gold", top_db=top_db)
+        assert db.shape == want.shape and db.max() == 0.0 and db.min() >= -top_db
+        # (values at the floor may sit on either side of it by the error of the deep bins)
+        d = np.abs(db - want)[want > -top_db + 1.0]
+        near = want >= want.max(axis=(-1, -2), keepdims=True) - NEAR_DB
+        assert np.max(np.abs(db - want)[near]) < 1e-3, f"dB-mel near error {np.max(np.abs(db - want)[near]):.3e}"
+        # YAMNet: any length, the tail padded to whole patches
+        n16 = int(rng.integers(400, 60000))
+        w = of.synth_batch(B, n16, 16000, first=6000 + case)
+        lm, patches = sed_amd.yamnet_log_mel(torch.from_numpy(w))
+        g_lm, g_p = of.yamnet_logmel(w, mode="gold")
+        r_lm, _ = of.yamnet_logmel(w, mode="ref32")
+        assert tuple(patches.shape) == g_p.shape, (tuple(patches.shape), g_p.shape)
+        check(lm.cpu().numpy(), g_lm, r_lm, ln_span, per_unit=2.0)
+        # magnitude spectrogram and whole-tensor top_db of the unfused modules; int16 against fp32
+        xt = torch.from_numpy(y).to(dev)
+        mag = sed_amd.Spectrogram(n_fft=n_fft, hop_length=hop, power=1.0).to(dev)(xt)[:, 0].cpu().numpy().astype(np.float64)
+        gold_p = of.power_spectrogram_gold(y, n_fft, hop)
+        rel = float(np.max(np.abs(mag ** 2 - gold_p) / np.maximum(gold_p.max(axis=-1, keepdims=True), 1e-30)))
+        assert rel < 4e-6, f"magnitude spectrogram {rel:.3e}"
+        sp = sed_amd.Spectrogram(n_fft=n_fft, hop_length=hop).to(dev)
+        lm_top = sed_amd.LogmelFilterBank(sr=sr, n_fft=n_fft, n_mels=n_mels, fmin=20, fmax=sr // 2, top_db=top_db).to(dev)
+        got_top = lm_top(sp(xt)).cpu().numpy()[:, 0]
+        melW = of.librosa_mel(sr, n_fft, n_mels, 20, sr // 2).T.astype(np.float64)
+        want_top = of.power_to_db(gold_p @ melW, top_db=top_db)
+        live = want_top > want_top.max() - top_db + 1.0
+        assert got_top.min() >= got_top.max() - top_db - 1e-4
+        near = want_top >= want_top.max(axis=-1, keepdims=True) - NEAR_DB
+        assert np.max(np.abs(got_top - want_top)[near & live]) < 1e-3, "LogmelFilterBank top_db"
+        s16 = of.f32_to_pcm16(y)
+        c16 = sed_amd.FrontendConfig.htsat(sample_rate=sr, window_size=n_fft, hop_size=hop, mel_bins=n_mels, pcm_kind=1, pcm_divisor=32767.0)
+        c32 = sed_amd.FrontendConfig.htsat(sample_rate=sr, window_size=n_fft, hop_size=hop, mel_bins=n_mels)
+        a = sed_amd.LogMelFrontend(c16)(torch.from_numpy(s16).to(dev))
+        b = sed_amd.LogMelFrontend(c32)(torch.from_numpy(of.pcm16_to_f32(s16)).to(dev))
+        assert torch.equal(a, b), "int16 input differs from the same samples as fp32"
+        # a strided batch (every second row of a larger buffer, rows longer than the clip)
+        big = torch.zeros(2 * B, n + 37, device=dev)
+        big[::2, :n] = xt
+        assert torch.equal(sed_amd.LogMelFrontend(c32)(big[::2, :n]), sed_amd.LogMelFrontend(c32)(xt)), "strided batch"
+        print(f"ok   {desc}", flush=True)
+        return True
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        print(f"FAIL {desc}: {type(e).__name__}: {e}\n{traceback.format_exc(limit=2)}", flush=True)
+        return False
+
+
 def kaldi_case(rng, case):
     sr = int(rng.choice([16000, 22050, 32000, 44100]))                  # 8 kHz frames are 256-point transforms: not built
     frame_length = float(rng.choice([20.0, 25.0, 32.0]))
@@ -160,7 +228,7 @@ def main():
     rng = np.random.default_rng(seed)
     bad = 0
     for case in range(cases):
-        ok = kaldi_case(rng, case) if case % 8 == 7 else one_case(rng, case, dev)
+        ok = kaldi_case(rng, case) if case % 8 == 7 else functions_case(rng, case, dev) if case % 8 == 3 else one_case(rng, case, dev)
         bad += not ok
     print(f"{cases - bad} of {cases} cases passed")
     sys.exit(1 if bad else 0)
