@@ -7,7 +7,9 @@ runs of random length (values placed on and next to the threshold), and checks, 
   * the CRNN chain: gaussian smoothing + threshold + region decode (+ gap merge at a random gap) against the oracle's
     smooth_and_threshold -> decode_predictions -> merge_close_events,
   * the detector decode (median filter, threshold, onset / offset rules) per stream,
-  * the single-stage YAMNet and HTS-AT argmax decoders and the clip label.
+  * the single-stage YAMNet and HTS-AT argmax decoders and the clip label,
+  * the multi-GPU tail (sharding.decode_and_exchange on one rank): records with caps that overflow, traces on either side
+    of the one-launch limit.
 """
 import os
 import sys
@@ -105,6 +107,45 @@ def argmax_case(rng, case):
     return desc, sum(len(v) for v in want_y)
 
 
+def records_case(rng, case):
+    """The multi-GPU tail in one call: smooth, threshold, run merge on a time table, records of (stream, class, onset frame,
+    offset frame) with a cap that may overflow, against the oracle's chain of the same steps."""
+    S, C = int(rng.integers(1, 40)), int(rng.integers(1, 7))
+    T = int(rng.choice([1, 2, 3, 20, 41, 510, 511, 862, int(rng.integers(4, 3000)), int(rng.integers(8000, 9500))]))
+    cap = int(rng.choice([1, 4, 16, 64, T // 2 + 1]))
+    smoothing = [None, "median3", "gauss"][int(rng.integers(3))]
+    hop = float(rng.choice([0.48, 0.02, 1.0 / 43.06640625]))
+    gap = float(rng.choice([0.0, 0.3, 0.5, 0.6, 1.0])) * (1.0 if hop > 0.1 else 0.1)
+    first = int(rng.integers(0, 5000))
+    desc = dict(case=case, kind="records", S=S, T=T, C=C, cap=cap, smoothing=smoothing, hop=round(hop, 4), gap=gap)
+    probs = field(rng, S, T, C)
+    table_host = [k * hop for k in range(T + 2)]
+    dev = torch.device("cuda", 0)
+    table = torch.tensor(table_host, dtype=torch.float64, device=dev)
+    got = sed_amd.sharding.decode_and_exchange(torch.from_numpy(probs).to(dev), table, gap, cap=cap, first_stream=first,
+                                               threshold=0.5, smoothing=smoothing).cpu().numpy()
+    if smoothing == "gauss":
+        act = od.smooth_and_threshold(probs)
+    else:
+        sm = od.median3_time(probs, 1) if smoothing == "median3" else probs
+        act = (sm > np.float32(0.5)).astype(int)
+    index = {t: k for k, t in enumerate(table_host)}
+    cap_in = T // 2 + 1
+    runs = np.zeros((S, C, cap_in, 2), np.int32)
+    counts = np.zeros((S, C), np.int32)
+    for s_ in range(S):
+        for c in range(C):
+            ev = [{"file": "f", "event_onset": table_host[a], "event_offset": table_host[b], "event_label": "e"}
+                  for a, b in od.contiguous_regions(act[s_, :, c])]
+            merged = od.merge_close_events(ev, gap)
+            counts[s_, c] = len(merged)
+            for k, m in enumerate(merged):
+                runs[s_, c, k] = (index[m["event_onset"]], index[m["event_offset"]])
+    want = od.pack_events(runs, counts, cap, first_stream=first)
+    assert got.shape == want.shape and np.array_equal(got, want), "records"
+    return desc, int(counts.sum())
+
+
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 120
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -112,7 +153,7 @@ def main():
     rng = np.random.default_rng(seed)
     bad = 0
     for case in range(cases):
-        fn = (crnn_case, detector_case, argmax_case)[case % 3]
+        fn = (crnn_case, detector_case, argmax_case, records_case)[case % 4]
         try:
             desc, n_ev = fn(rng, case)
             print(f"ok   {desc} events {n_ev}", flush=True)
