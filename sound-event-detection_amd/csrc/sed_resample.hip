@@ -492,6 +492,12 @@ extern "C" int sed_resampler_create(int32_t orig_sr, int32_t target_sr, sed_resa
         r->dma_rounds = (int32_t)rounds;
       }
     }
+  if (!r->any && r->threads > max_threads && r->dma_groups == 0) {  // more than 512 phases, and no LDS-DMA shape for them either
+    r->any = true;
+    r->tp = r->taps;
+    r->groups = 0;
+    r->threads = 256;
+  }
   r->b64 = r->dma_groups > 0 && r->qstep % 2 == 0 && r->taps < r->tp;
   if (r->b64) {
     // a lane that skips an odd first sample reads one sample past its window (coefficient 0): one more staged sample

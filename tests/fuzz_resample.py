@@ -32,9 +32,13 @@ def main():
             orig, target = int(rng.choice(RATES)), int(rng.choice(RATES))
         else:
             a, b = int(rng.integers(1, 40)), int(rng.integers(1, 40))
+            if rng.random() < 0.25:
+                b = int(rng.integers(500, 1100))                       # many phases, with and without whole half wavefronts
             base = int(rng.choice([100, 250, 1000, 441]))
             orig, target = a * base, b * base
         n = int(rng.choice([1, 2, 7, int(rng.integers(1, 300)), int(rng.integers(300, 5000)), int(rng.integers(5000, 200000))]))
+        if target > 8 * orig:
+            n = min(n, 4000)                                           # (the output is target / orig times as long)
         B = int(rng.integers(1, 5))
         i16 = bool(rng.random() < 0.3)
         g = math.gcd(orig, target)
