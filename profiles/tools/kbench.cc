@@ -70,12 +70,15 @@ int main(int argc, char** argv) {
   std::string cfgname = "htsat";
   int steps = 200, warm = 30;
   long long batch = 0;  // 0: the flavour's own batch
+  int mels = 0, pre = -1;
   std::vector<const char*> libs;
   for (int i = 1; i < argc; ++i) {
     if (!strcmp(argv[i], "-c") && i + 1 < argc) cfgname = argv[++i];
     else if (!strcmp(argv[i], "-n") && i + 1 < argc) steps = atoi(argv[++i]);
     else if (!strcmp(argv[i], "-w") && i + 1 < argc) warm = atoi(argv[++i]);
     else if (!strcmp(argv[i], "-b") && i + 1 < argc) batch = atoll(argv[++i]);
+    else if (!strcmp(argv[i], "-M") && i + 1 < argc) mels = atoi(argv[++i]);        // experiments: another mel count
+    else if (!strcmp(argv[i], "-P") && i + 1 < argc) pre = atoi(argv[++i]);         // bit 0: DC removal, bit 1: pre-emphasis
     else libs.push_back(argv[i]);
   }
   if (libs.empty()) { fprintf(stderr, "usage: kbench [-c cfg] [-n steps] lib.so ...\n"); return 2; }
@@ -111,6 +114,8 @@ int main(int argc, char** argv) {
   } else { fprintf(stderr, "unknown cfg %s\n", cfgname.c_str()); return 2; }
 
   if (batch > 0) B = batch;
+  if (mels > 0) c.n_mels = mels;
+  if (pre >= 0) { c.remove_dc = pre & 1; c.preemphasis = (pre & 2) ? 0.97f : 0.0f; }
   // deterministic noise + a tone + a stretch of silence
   const size_t n = (size_t)B * L;
   const size_t esz = i16 ? 2 : 4;
