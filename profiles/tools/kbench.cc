@@ -1,6 +1,6 @@
 // Times sed_logmel_forward of one or more builds of libsedhip.so on the headline workload (or another flavour) and
 // compares their outputs with the first build's.  Diagnostic tool:
-//   hipcc -O2 -o kbench kbench.cc -ldl ;  ./kbench [-c htsat|htsat_i16|yamnet|crnn|dbmel|kaldi|htsat1h] [-n steps] [-b clips] lib1.so [lib2.so ...]
+//   hipcc -O2 -o kbench kbench.cc -ldl ;  ./kbench [-c htsat|htsat_i16|htsat44|yamnet|crnn|dbmel|kaldi|kaldi44|htsat1h] [-n steps] [-b clips] lib1.so [lib2.so ...]
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
@@ -70,13 +70,14 @@ int main(int argc, char** argv) {
   std::string cfgname = "htsat";
   int steps = 200, warm = 30;
   long long batch = 0;  // 0: the flavour's own batch
-  int mels = 0, pre = -1;
+  int mels = 0, pre = -1, hop = 0;
   std::vector<const char*> libs;
   for (int i = 1; i < argc; ++i) {
     if (!strcmp(argv[i], "-c") && i + 1 < argc) cfgname = argv[++i];
     else if (!strcmp(argv[i], "-n") && i + 1 < argc) steps = atoi(argv[++i]);
     else if (!strcmp(argv[i], "-w") && i + 1 < argc) warm = atoi(argv[++i]);
     else if (!strcmp(argv[i], "-b") && i + 1 < argc) batch = atoll(argv[++i]);
+    else if (!strcmp(argv[i], "-H") && i + 1 < argc) hop = atoi(argv[++i]);         // experiments: another hop
     else if (!strcmp(argv[i], "-M") && i + 1 < argc) mels = atoi(argv[++i]);        // experiments: another mel count
     else if (!strcmp(argv[i], "-P") && i + 1 < argc) pre = atoi(argv[++i]);         // bit 0: DC removal, bit 1: pre-emphasis
     else libs.push_back(argv[i]);
@@ -89,12 +90,13 @@ int main(int argc, char** argv) {
   c.window_kind = SED_WINDOW_HANN_PERIODIC;
   c.pcm_kind = SED_PCM_F32;
   c.pcm_divisor = 32767.0f;
-  if (cfgname == "htsat" || cfgname == "htsat_i16" || cfgname == "htsat1h") {
+  if (cfgname == "htsat" || cfgname == "htsat_i16" || cfgname == "htsat1h" || cfgname == "htsat44") {
     c.sample_rate = 32000; c.n_fft = 1024; c.win_length = 1024; c.hop = 320; c.center = 1; c.pad_mode = SED_PAD_REFLECT;
     c.win_align = SED_WIN_CENTER; c.spectrum = SED_SPEC_POWER; c.mel_kind = SED_MEL_SLANEY; c.n_mels = 64;
     c.fmin = 50; c.fmax = 14000; c.log_kind = SED_LOG_DB10; c.amin = 1e-10f; c.ref = 1.0f;
     if (cfgname == "htsat_i16") { i16 = true; c.pcm_kind = SED_PCM_I16; }
     if (cfgname == "htsat1h") { B = 4; L = 3600LL * 32000; }
+    if (cfgname == "htsat44") { c.sample_rate = 44100; B = 128; L = 882000; }  // the rate and clip length the reference runs (src/models/htsat/model.py:171-186)
   } else if (cfgname == "yamnet") {
     c.sample_rate = 16000; c.n_fft = 512; c.win_length = 400; c.hop = 160; c.center = 0; c.win_align = SED_WIN_LEFT;
     c.tail_min_samples = 15600; c.tail_hop_samples = 7680; c.spectrum = SED_SPEC_MAGNITUDE; c.mel_kind = SED_MEL_HTK_TF;
@@ -106,6 +108,11 @@ int main(int argc, char** argv) {
     if (cfgname == "crnn") { c.hop = 1024; c.spectrum = SED_SPEC_MAGNITUDE; c.n_mels = 40; c.log_kind = SED_LOG_LN; c.ln_offset = 1e-9f; }
     else { c.hop = 512; c.spectrum = SED_SPEC_POWER; c.n_mels = 64; c.log_kind = SED_LOG_DB10; c.amin = 1e-10f; c.ref = 1.0f; }
     B = 128; L = 441000;
+  } else if (cfgname == "kaldi44") {  // the Audio-Mamba input at the rate of the reference's files (torchaudio.load gives 44.1 kHz)
+    c.sample_rate = 44100; c.n_fft = 2048; c.win_length = 1102; c.hop = 441; c.center = 0; c.win_align = SED_WIN_LEFT;
+    c.window_kind = SED_WINDOW_HANN_SYMMETRIC; c.remove_dc = 1; c.preemphasis = 0.97f; c.spectrum = SED_SPEC_POWER;
+    c.mel_kind = SED_MEL_KALDI; c.n_mels = 128; c.fmin = 20; c.fmax = 0; c.log_kind = SED_LOG_LN_FLOOR; c.amin = 1.1920929e-07f;
+    B = 256; L = 441000;
   } else if (cfgname == "kaldi") {
     c.sample_rate = 16000; c.n_fft = 512; c.win_length = 400; c.hop = 160; c.center = 0; c.win_align = SED_WIN_LEFT;
     c.window_kind = SED_WINDOW_HANN_SYMMETRIC; c.remove_dc = 1; c.preemphasis = 0.97f; c.spectrum = SED_SPEC_POWER;
@@ -115,6 +122,7 @@ int main(int argc, char** argv) {
 
   if (batch > 0) B = batch;
   if (mels > 0) c.n_mels = mels;
+  if (hop > 0) c.hop = hop;
   if (pre >= 0) { c.remove_dc = pre & 1; c.preemphasis = (pre & 2) ? 0.97f : 0.0f; }
   // deterministic noise + a tone + a stretch of silence
   const size_t n = (size_t)B * L;

@@ -164,6 +164,8 @@ int main() {
   if (check_mel_schedule(16000, 512, 128, 20, 0, 2, 260) > 1e-12) bad = 1;
   if (check_mel_schedule(32000, 1024, 128, 0, 16000, 0, 516) > 1e-12) bad = 1;
   if (check_mel_schedule(22050, 2048, 17, 300, 9000, 1, 1028) > 1e-12) bad = 1;
+  if (check_mel_schedule(44100, 1024, 64, 50, 14000, 0, 516) > 1e-12) bad = 1;  // HTS-AT at the rate the reference runs it
+  if (check_mel_schedule(44100, 2048, 128, 20, 0, 2, 1028) > 1e-12) bad = 1;    // Kaldi fbank at the rate of the reference's files
   auto report = [&](int n_fft, const char* what, double e) {
     std::printf("%d %s max_rel_err %.3e\n", n_fft, what, e);
     if (!(e < 2e-6)) bad = 1;

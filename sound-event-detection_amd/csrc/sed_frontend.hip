@@ -1403,6 +1403,12 @@ static int launch_front_shape(const sed_plan* pl, FrontParams p, int64_t B, hipS
     waves = (int)std::min<int64_t>(waves, std::max<int64_t>(floor_waves, (total_groups + pl->num_cus - 1) / pl->num_cus));
   }
   const size_t lds_bytes = (size_t)(p.off_wave + waves * p.wave_floats) * sizeof(float);
+#ifdef SED_DIAGNOSTIC_BUILD
+  static const bool debug_shape = getenv("SED_DEBUG_SHAPE") != nullptr;
+  if (debug_shape)
+    fprintf(stderr, "shape: image %d floats, region %d (span %d, exchange %d, power rows %d, partial sums at %d + %d), %d wavefronts, %zu bytes\n",
+            p.image_floats, p.wave_floats, span_floats, G::FPW * G::XFR, G::FPW * G::PP, p.part_off, part_floats, waves, lds_bytes);
+#endif
   if (lds_bytes > 160 * 1024) return SED_ERR_BAD_ARG;
 #ifdef SED_ONLY_BENCH  // diagnostic builds: one instantiation only, seconds to compile
   if ((p.pcm_kind & ~kPcmDiv3) == SED_PCM_I16 || p.seg_off) return SED_ERR_BAD_ARG;
@@ -1505,8 +1511,9 @@ static int launch_front(const sed_plan* pl, const FrontParams& p, int64_t B, hip
     const bool two = p.n_quads > 16;
     // (sets, steps of the first n_hi sets, steps of the others, n_hi, most positions per quad, two gather rounds)
     auto is = [&](int sets, int u, int ulo, int nhi, int maxpos, bool rounds2) {
-      return p.hop % 4 == 0 && p.mel_sets == sets && p.mel_u == u && p.mel_ulo == ulo && p.mel_nhi == nhi && p.mel_maxpos == maxpos &&
-             two == rounds2;  // (hops off the 16-byte grid run the general kernel)
+      // (hops off the 16-byte grid run the general kernel, except with frame conditioning, which reads sample by sample)
+      return (PRE || p.hop % 4 == 0) && p.mel_sets == sets && p.mel_u == u && p.mel_ulo == ulo && p.mel_nhi == nhi &&
+             p.mel_maxpos == maxpos && two == rounds2;
     };
     if constexpr (G::NFFT == 1024 && !MAG && !PRE) {  // HTS-AT: Slaney 64 mel, 50..14000 Hz at 32 kHz
 #ifdef SED_EST_MEL_U  // timing experiments: a shorter chain per accumulator set than the plan's schedule has (results are then garbage)
@@ -1514,6 +1521,8 @@ static int launch_front(const sed_plan* pl, const FrontParams& p, int64_t B, hip
 #endif
       if (is(2, 6, 4, 1, 5, false) && p.hop == 320) return launch_front_shape<G, MAG, SPEC_OUT, PRE, MelStatic<2, 6, 5, 1, 320, 4, 1>>(pl, p, B, stream);
       if (is(2, 6, 4, 1, 5, false)) return launch_front_shape<G, MAG, SPEC_OUT, PRE, MelStatic<2, 6, 5, 1, 0, 4, 1>>(pl, p, B, stream);
+      // the same model at 44.1 kHz, the rate the reference itself runs it at (src/models/htsat/model.py:171-186)
+      if (is(4, 4, 1, 1, 6, false) && p.hop == 320) return launch_front_shape<G, MAG, SPEC_OUT, PRE, MelStatic<4, 4, 6, 1, 320, 1, 1>>(pl, p, B, stream);
     }
     if constexpr (G::NFFT == 512 && MAG && !PRE) {  // YAMNet: HTK 64 mel, 125..7500 Hz at 16 kHz
       if (is(2, 4, 2, 1, 3, false)) return launch_front_shape<G, MAG, SPEC_OUT, PRE, MelStatic<2, 4, 3, 1, 0, 2, 1>>(pl, p, B, stream);
@@ -1526,6 +1535,9 @@ static int launch_front(const sed_plan* pl, const FrontParams& p, int64_t B, hip
     }
     if constexpr (G::NFFT == 512 && !MAG && PRE) {  // Kaldi fbank: 128 mel, 20..8000 Hz at 16 kHz
       if (is(3, 3, 2, 1, 3, true)) return launch_front_shape<G, MAG, SPEC_OUT, PRE, MelStatic<3, 3, 3, 2, 0, 2, 1>>(pl, p, B, stream);
+    }
+    if constexpr (G::NFFT == 2048 && !MAG && PRE) {  // the same at 44.1 kHz, the rate of the reference's files (25 ms = 1102 samples)
+      if (is(4, 11, 4, 1, 6, true)) return launch_front_shape<G, MAG, SPEC_OUT, PRE, MelStatic<4, 11, 6, 2, 0, 4, 1>>(pl, p, B, stream);
     }
   }
   return launch_front_shape<G, MAG, SPEC_OUT, PRE, MelDynamic>(pl, p, B, stream);

@@ -304,7 +304,9 @@ def test_kaldi_fbank_and_aum_wav2fbank():
     import sed_amd
     _dev()
     span = NEAR_DB / 10.0 * np.log(10.0)                                 # 60 dB of power in nepers
-    for sr, n, mel in ((16000, 160000, 128), (32000, 100000, 128), (44100, 120000, 64)):
+    # (44.1 kHz with 128 bins is the rate of the reference's own files, torchaudio.load at dataloader.py:98: 1102-sample
+    # frames every 441 samples in 2048-point transforms)
+    for sr, n, mel in ((16000, 160000, 128), (32000, 100000, 128), (44100, 120000, 64), (44100, 100000, 128)):
         x = of.synth_batch(3, n, sr, first=70) + 0.02                    # a DC offset for remove_dc_offset to remove
         got = sed_amd.kaldi_fbank(torch.from_numpy(x), sample_frequency=sr, num_mel_bins=mel, frame_shift=10,
                                   htk_compat=True, use_energy=False, window_type="hanning", dither=0.0)
