@@ -649,15 +649,33 @@ def kaldi_fbank(waveform, sample_frequency=16000.0, num_mel_bins=23, frame_lengt
     return out[0] if x.shape[0] == 1 else out
 
 
-def wav2fbank(waveform, sr, melbins=128, target_length=1024, fshift=10, norm_mean=None, norm_std=None):
+def wav2fbank(waveform, sr, melbins=128, target_length=1024, fshift=10, norm_mean=None, norm_std=None, lengths=None):
     """AudiosetDataset._wav2fbank + the normalisation of __getitem__ (external/audio_mamba/src/dataloader.py:94-152,
     219-221) for one clip (1, L) or a batch (B, L): mean removal, Kaldi fbank, zero-pad / cut to target_length frames,
-    then (x - norm_mean) / (2 norm_std) when both are given.  Returns (B, target_length, melbins)."""
+    then (x - norm_mean) / (2 norm_std) when both are given.  Returns (B, target_length, melbins).
+
+    lengths (B,): the clips are events of different lengths in a zero-padded batch (what cut_events returns).  The
+    reference reads every event from a file of its own, so a clip of n samples has 1 + (n - window) // shift frames and
+    zeros behind them; the same here: the mean is that of the clip's own samples, and frames that reach past them are
+    zero before the normalisation (frames in front of them only ever read the clip's own samples)."""
     x, _ = _as_cuda_batch(waveform)
-    x = x - x.mean(dim=1, keepdim=True)
+    if lengths is None:
+        x = x - x.mean(dim=1, keepdim=True)
+    else:
+        n_valid = torch.as_tensor(lengths, device=x.device).to(torch.int64).clamp(min=0, max=x.shape[1])
+        if n_valid.shape != (x.shape[0],):
+            raise ValueError("lengths must hold one sample count per clip")
+        inside = torch.arange(x.shape[1], device=x.device)[None, :] < n_valid[:, None]
+        x = torch.where(inside, x, torch.zeros((), dtype=x.dtype, device=x.device))
+        x = x - x.sum(dim=1, keepdim=True) / n_valid.clamp(min=1)[:, None].to(x.dtype)
     fb = kaldi_fbank(x, sample_frequency=sr, num_mel_bins=melbins, frame_shift=fshift, htk_compat=True)
     if fb.dim() == 2:
         fb = fb[None]
+    if lengths is not None:
+        win, hop = int(int(round(sr)) * 25.0 * 0.001), int(int(round(sr)) * fshift * 0.001)
+        frames = torch.where(n_valid >= win, 1 + (n_valid - win) // hop, torch.zeros_like(n_valid))
+        keep = torch.arange(fb.shape[1], device=x.device)[None, :] < frames[:, None]
+        fb = torch.where(keep[:, :, None], fb, torch.zeros((), dtype=fb.dtype, device=fb.device))
     n = fb.shape[1]
     if n < target_length:
         fb = torch.nn.functional.pad(fb, (0, 0, 0, target_length - n))

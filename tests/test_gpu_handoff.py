@@ -144,3 +144,37 @@ def test_logmel_of_events_equals_cut_then_front_end():
         sed_amd.logmel_of_events(fe16, x[:, :n], sr, events, 96000)                  # sample type of the plan
     with pytest.raises(ValueError):
         sed_amd.logmel_of_events(sed_amd.LogMelFrontend(sed_amd.FrontendConfig.yamnet()), x[:, :n], 16000, events[:2], 48000)
+
+
+def test_events_handed_to_the_audio_mamba_front_end():
+    """Detector events -> Audio-Mamba input (main.py:123-127 cuts every event into a file of its own, which
+    external/audio_mamba/src/dataloader.py:94-152, 219-221 then reads: fbank of the event's own samples, zero frames up to
+    target_length, normalisation).  Here: cut_events gives the zero-padded batch and the lengths, wav2fbank(lengths=...) the
+    features; compared event by event with the restatement on the event's own samples."""
+    import sed_amd
+    from oracle import frontend as of
+    dev = torch.device("cuda", 0)
+    sr = 44100                                                            # the rate of the reference's files
+    x = of.synth_batch(3, 6 * sr, sr, first=330)
+    events = [(0, 0.5, 2.75), (1, 1.0, 1.02), (2, 0.0, 5.99), (1, 3.3, 4.0), (0, 5.9, 7.5), (2, 2.0, 2.0)]  # one shorter than a frame, one running past the end, one empty
+    clips, lengths = sed_amd.cut_events(torch.from_numpy(x).to(dev), sr, events)[:2]
+    fb = sed_amd.wav2fbank(clips, sr, melbins=128, target_length=256, norm_mean=-4.2677393, norm_std=4.5689974,
+                           lengths=lengths).cpu().numpy()
+    assert fb.shape == (len(events), 256, 128)
+    span = 60.0 / 10.0 * np.log(10.0) / (2 * 4.5689974)
+    win, hop = int(sr * 0.025), int(sr * 0.010)
+    pad_value = (0.0 + 4.2677393) / (2 * 4.5689974)
+    for e, (s, a, b) in enumerate(events):
+        piece = x[s, int(a * sr):int(b * sr)]
+        assert int(lengths[e]) == len(piece)
+        if len(piece) < win:
+            assert np.allclose(fb[e], pad_value, rtol=0, atol=1e-6)        # no frame at all: zeros before the normalisation
+            continue
+        want = of.aum_wav2fbank(piece[None], sr, 128, 256, 10, -4.2677393, 4.5689974, mode="gold")[0]
+        T = min(256, 1 + (len(piece) - win) // hop)
+        near = want[:T] >= want[:T].max(-1, keepdims=True) - span
+        assert np.max(np.abs(fb[e, :T] - want[:T])[near]) < 1e-3 / (2 * 4.5689974) + 1e-6, e
+        assert np.allclose(fb[e, T:], want[T:], rtol=0, atol=1e-6), e     # zero frames behind the event
+    # without lengths the batch is what it looks like: clips of the padded length
+    dense = sed_amd.wav2fbank(clips, sr, melbins=128, target_length=256)
+    assert dense.shape == (len(events), 256, 128)
