@@ -152,6 +152,18 @@ int sed_logmel_forward(const sed_plan* plan, const void* pcm, int64_t B, int64_t
 int sed_logmel_forward_segments(const sed_plan* plan, const void* pcm, const int64_t* seg_off, const int32_t* seg_len,
                                 int64_t n_segments, int64_t L, float* out, int64_t out_stride_b, void* stream);
 
+/* The same hand-off with every segment framed as a RECORDING OF ITS OWN, as stage 2 of the reference sees it: each
+ * event file is loaded at its natural length and fed alone (src/models/htsat/data.py:138-146, batch_size = 1 at
+ * src/models/htsat/classification.py:55-59), so the padding rule of the STFT applies at the event's own end
+ * (htsat.py:763, center=True, pad_mode='reflect') and the event has its own number of frames.  Segment e, n = seg_len[e]
+ * samples (clamped to L), gets frames_e = 1 + n / hop frames (center) or 1 + (n - frame) / hop (not centred), and rows
+ * [0, frames_e) of out[e] equal sed_logmel_forward on the n samples alone, bit for bit.  Rows from frames_e on are NOT
+ * WRITTEN (clear the buffer beforehand if they are read).  A segment too short for the plan (n <= n_fft/2 under reflect
+ * padding, n < frame when not centred, n = 0) gets no row.  L is only the row capacity: out is
+ * [n_segments][sed_plan_num_frames(plan, L)][n_mels].  Arguments and errors otherwise as sed_logmel_forward_segments. */
+int sed_logmel_forward_segments_own(const sed_plan* plan, const void* pcm, const int64_t* seg_off, const int32_t* seg_len,
+                                    int64_t n_segments, int64_t L, float* out, int64_t out_stride_b, void* stream);
+
 /* Unfused parity path: |STFT|^2 (or |STFT|), replaces spectrogram_extractor(x) at htsat.py:763.
  * out: fp32 [B][T][n_fft/2+1], clip b at out + b*out_stride_b. */
 int sed_spectrogram_forward(const sed_plan* plan, const void* pcm, int64_t B, int64_t L, int64_t pcm_stride,
@@ -281,6 +293,13 @@ int sed_cut_events(const void* pcm, int32_t pcm_kind, float pcm_divisor, int64_t
  * img[b][0][r*M + f][u] = y[b][r*(target_T/freq_ratio) + u][f].  T <= target_T, target_T % freq_ratio == 0. */
 int sed_htsat_wav2img(const float* logmel, int64_t B, int64_t T, int64_t M, int64_t target_T, int32_t freq_ratio,
                       float* img, void* stream);
+
+/* The same for clips with frame counts of their own (events of different lengths, each stretched to the image as the file
+ * of that event would be, htsat.py:729-744 with x.shape[2] = frames[b]): logmel fp32 [B][T][M] holds frames[b] <= T rows
+ * for clip b (frames: int32 DEVICE array [B]; values are clamped to [0, T]), and the interpolation of clip b runs over
+ * those rows only.  A clip with no frame gives an image of zeros. */
+int sed_htsat_wav2img_ragged(const float* logmel, const int32_t* frames, int64_t B, int64_t T, int64_t M, int64_t target_T,
+                             int32_t freq_ratio, float* img, void* stream);
 
 /* repeat_wat2img (external/hts_audio_transformer/model/htsat.py:747-760; the enable_repeat_mode branch :783-805):
  * the same interpolation to target_T frames, then the spec_size frames from cur_pos on, transposed and stacked

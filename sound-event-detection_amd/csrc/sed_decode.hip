@@ -567,17 +567,29 @@ extern "C" int sed_cut_events(const void* pcm, int32_t pcm_kind, float pcm_divis
 __device__ __forceinline__ float cubic1(float x, float A) { return ((A + 2.0f) * x - (A + 3.0f)) * x * x + 1.0f; }
 __device__ __forceinline__ float cubic2(float x, float A) { return ((A * x - 5.0f * A) * x + 8.0f * A) * x - 4.0f * A; }
 
+// frames (optional): clip b holds frames[b] of the T rows of its slot, and its interpolation runs over those alone.
 __global__ void __launch_bounds__(256) wav2img_kernel(const float* x, int T, int M, int target_T, int ratio, int seg,
-                                                      int col0, int col_step, float scale, float* img) {
+                                                      int col0, int col_step, float scale, float* img,
+                                                      const int32_t* frames) {
   extern __shared__ float rows[];  // input frames [n_rows][M + 1]
   const int tiles = (seg + 63) / 64;
   const int tile = blockIdx.x % tiles, r = blockIdx.x / tiles, b = blockIdx.y;
   const int u0 = tile * 64, t0 = col0 + r * col_step + u0;  // first interpolated frame of this tile
   const int n_out = min(64, seg - u0);
+  const int slot = T;  // rows between clips
+  if (frames) {
+    T = min(max(frames[b], 0), slot);
+    if (T == 0) {  // a clip without frames: zeros
+      for (int i = threadIdx.x; i < n_out * M; i += 256)
+        img[(((int64_t)b * ratio + r) * M + i / n_out) * seg + u0 + i % n_out] = 0.0f;
+      return;
+    }
+    scale = target_T > 1 ? (float)(T - 1) / (float)(target_T - 1) : 0.0f;
+  }
   const int lo = max(0, (int)floorf(scale * (float)t0) - 1);
   const int hi = min(T - 1, (int)floorf(scale * (float)(t0 + n_out - 1)) + 2);
   const int n_rows = hi - lo + 1, pitch = M + 1;
-  const float* src = x + ((int64_t)b * T + lo) * M;
+  const float* src = x + ((int64_t)b * slot + lo) * M;
   // staging: 16 bytes per load when the rows allow it (the tile's rows are contiguous in memory)
   if (M % 4 == 0 && ((uintptr_t)src & 15) == 0) {
     for (int i4 = threadIdx.x; i4 < n_rows * (M / 4); i4 += 256) {
@@ -648,7 +660,23 @@ extern "C" int sed_htsat_wav2img(const float* logmel, int64_t B, int64_t T, int6
   const int seg = (int)(target_T / freq_ratio), tiles = (seg + 63) / 64;
   const size_t lds = (size_t)(64 + 6) * (M + 1) * sizeof(float);
   hipLaunchKernelGGL(wav2img_kernel, dim3((unsigned)(tiles * freq_ratio), (unsigned)B), dim3(256), lds,
-                     (hipStream_t)stream, logmel, (int)T, (int)M, (int)target_T, (int)freq_ratio, seg, 0, seg, scale, img);
+                     (hipStream_t)stream, logmel, (int)T, (int)M, (int)target_T, (int)freq_ratio, seg, 0, seg, scale, img,
+                     (const int32_t*)nullptr);
+  return hip_status(hipGetLastError());
+}
+
+extern "C" int sed_htsat_wav2img_ragged(const float* logmel, const int32_t* frames, int64_t B, int64_t T, int64_t M,
+                                        int64_t target_T, int32_t freq_ratio, float* img, void* stream) {
+  if (B < 0 || T < 1 || M < 1 || M > 512 || freq_ratio < 1 || target_T < T || target_T % freq_ratio != 0)
+    return SED_ERR_BAD_ARG;
+  if (B > 65535 || target_T > INT32_MAX / 2) return SED_ERR_BAD_ARG;
+  if (B == 0) return SED_OK;
+  if (!logmel || !img || !frames) return SED_ERR_BAD_ARG;
+  const int seg = (int)(target_T / freq_ratio), tiles = (seg + 63) / 64;
+  const size_t lds = (size_t)(64 + 6) * (M + 1) * sizeof(float);
+  hipLaunchKernelGGL(wav2img_kernel, dim3((unsigned)(tiles * freq_ratio), (unsigned)B), dim3(256), lds,
+                     (hipStream_t)stream, logmel, (int)T, (int)M, (int)target_T, (int)freq_ratio, seg, 0, seg, 0.0f, img,
+                     frames);
   return hip_status(hipGetLastError());
 }
 
@@ -664,7 +692,7 @@ extern "C" int sed_htsat_repeat2img(const float* logmel, int64_t B, int64_t T, i
   const size_t lds = (size_t)(64 + 6) * (M + 1) * sizeof(float);
   hipLaunchKernelGGL(wav2img_kernel, dim3((unsigned)(tiles * repeats), (unsigned)B), dim3(256), lds,
                      (hipStream_t)stream, logmel, (int)T, (int)M, (int)target_T, (int)repeats, (int)spec_size,
-                     (int)cur_pos, 0, scale, img);
+                     (int)cur_pos, 0, scale, img, (const int32_t*)nullptr);
   return hip_status(hipGetLastError());
 }
 

@@ -77,6 +77,9 @@ struct FrontParams {
   // segment mode (SEG kernels): clip b is seg_len[b] samples starting at element seg_off[b] of pcm, followed by zeros up to L
   const int64_t* seg_off;
   const int32_t* seg_len;
+  // seg_own: every segment is framed as a recording of its own length (padding rule at its own end, only its own frames
+  // written): a segment of n samples has 0 frames if n < own_min, else 1 + (n - own_sub) / hop
+  int32_t seg_own, own_min, own_sub;
   unsigned long long* stamps;  // SED_TIMELINE builds only
 };
 
@@ -173,18 +176,19 @@ struct __attribute__((packed, aligned(2))) i16x4_u { short x, y, z, w; };
 // The fast path issues its loads in batches of 8 x 4 samples per lane before the first LDS store, with clamped
 // (never predicated) addresses: a load under a divergent branch would be waited for on its own.
 // HOP / SKEW: the skewed layout (groups of 4 samples never straddle a hop: both are multiples of 4).
-// The clip starts at element clip_off of the PCM buffer and holds `valid` stored samples (then zeros up to p.L).
+// The clip starts at element clip_off of the PCM buffer and holds `valid` stored samples (then zeros up to clipL, the
+// length the padding rule is applied to).
 template <bool I16, int HOP = 0, int SKEW = 0>
-__device__ __forceinline__ void stage_span(const FrontParams& p, float* dst, int64_t clip_off, int64_t valid, int64_t s0, int count,
-                                           int lane) {
+__device__ __forceinline__ void stage_span(const FrontParams& p, float* dst, int64_t clip_off, int64_t valid, int64_t clipL,
+                                           int64_t s0, int count, int lane) {
   auto at = [](int i) { if constexpr (SKEW > 0) return i + SKEW * (i / HOP); else return i; };
   // (int16 plans whose divisor failed the three-instruction check take the out-of-line path with the IEEE division)
   bool fast = s0 >= 0 && s0 + count <= valid;
   if constexpr (I16) fast = fast && (p.pcm_kind & kPcmDiv3);
   if (!fast) {
-    if constexpr (I16) stage_span_edges<int16_t>((const int16_t*)p.pcm + clip_off, p.pcm_div, p.L, valid, p.pad_mode, dst, s0, count,
+    if constexpr (I16) stage_span_edges<int16_t>((const int16_t*)p.pcm + clip_off, p.pcm_div, clipL, valid, p.pad_mode, dst, s0, count,
                                                  lane, SKEW > 0 ? HOP : 1, SKEW);
-    else stage_span_edges<float>((const float*)p.pcm + clip_off, 1.0f, p.L, valid, p.pad_mode, dst, s0, count, lane,
+    else stage_span_edges<float>((const float*)p.pcm + clip_off, 1.0f, clipL, valid, p.pad_mode, dst, s0, count, lane,
                                  SKEW > 0 ? HOP : 1, SKEW);
   } else if constexpr (!I16) {
     const float* src = (const float*)p.pcm + clip_off + s0;
@@ -642,13 +646,21 @@ stft_mel_kernel(const FrontParams p) {
 #else
       const int64_t s0 = (int64_t)f0 * p.hop - p.pad_left;
 #endif
+      int Tb = p.T;  // frames of clip b that are written
       if constexpr (SEG && !SPEC_OUT) {
         // A group whose whole span lies in the zeros behind the segment (and, at the clip's end, whose reflected samples do
         // too): nothing to fetch and nothing to transform.  (A span ordered early always lies inside the stored samples.)
+        // Segments framed as recordings of their own: the groups behind the segment's own frames.
         const int64_t valid = min((int64_t)p.seg_len[b], p.L);
         const int64_t last = s0 + p.span - 1;  // last sample of the span in the virtual clip
-        const bool all_zero = !staged && (valid <= 0 || (s0 >= valid && (last < p.L || p.pad_mode != SED_PAD_REFLECT ||
-                                                                         2 * (p.L - 1) - last >= valid)));
+        bool all_zero;
+        if (p.seg_own) {
+          Tb = valid < p.own_min ? 0 : 1 + (int)((unsigned)(valid - p.own_sub) / (unsigned)p.hop);
+          all_zero = !staged && f0 >= Tb;
+        } else {
+          all_zero = !staged && (valid <= 0 || (s0 >= valid && (last < p.L || p.pad_mode != SED_PAD_REFLECT ||
+                                                                2 * (p.L - 1) - last >= valid)));
+        }
         if (all_zero) {
           if (held) {
             static_for<0, kGroups>([&](auto Gf) {
@@ -658,7 +670,7 @@ stft_mel_kernel(const FrontParams p) {
             });
           }
           static_for<0, kGroups>([&](auto Gf) { hval[decltype(Gf)::value][0] = zc[0]; hval[decltype(Gf)::value][1] = zc[1]; });
-          held = true;
+          held = !p.seg_own;  // (rows behind a segment's own frames are not written)
           hdst = p.out + (int64_t)b * p.out_stride_b + (int64_t)f0 * p.n_mels;
           hvalid = min(G::FPW, p.T - f0);
           gi = group_of(__builtin_amdgcn_readfirstlane(taken));
@@ -679,7 +691,9 @@ stft_mel_kernel(const FrontParams p) {
           if constexpr (SKEW > 0) stage_span_dma_skewed<G, Mel::HOP, SKEW>(p, X, coff, s0, lane);
           else if (!SED_SKIP(1)) stage_span_dma(p, X, coff, s0, lane);
         } else {
-          stage_span<I16, Mel::HOP, SKEW>(p, X, coff, valid, s0, p.span, lane);
+          int64_t clipL = p.L;
+          if constexpr (SEG) { if (p.seg_own) clipL = valid; }
+          stage_span<I16, Mel::HOP, SKEW>(p, X, coff, valid, clipL, s0, p.span, lane);
         }
       }
       SED_STAMP(0)
@@ -758,7 +772,7 @@ stft_mel_kernel(const FrontParams p) {
       for (int k = G::NBINS + l; k < G::PP; k += G::LPF) pw[k] = 0.0f;  // row padding read (with zero weight) by the mel stage
       wave_phase_fence();
       SED_STAMP(4)
-      const int nvalid = min(G::FPW, p.T - f0);
+      const int nvalid = min(G::FPW, Tb - f0);
       // the group after this one: the one just taken from the queue
       gi = group_of(__builtin_amdgcn_readfirstlane(taken));
       const bool more = gi < g_end;
@@ -1545,7 +1559,8 @@ static int launch_front(const sed_plan* pl, const FrontParams& p, int64_t B, hip
 
 template <bool SPEC_OUT>
 static int front_forward(const sed_plan* pl, const void* pcm, int64_t B, int64_t L, int64_t pcm_stride, float* out,
-                         int64_t out_stride_b, void* stream, const int64_t* seg_off = nullptr, const int32_t* seg_len = nullptr) {
+                         int64_t out_stride_b, void* stream, const int64_t* seg_off = nullptr, const int32_t* seg_len = nullptr,
+                         bool seg_own = false) {
   if (!pl || B < 0 || L < 0) return SED_ERR_BAD_ARG;
   const int64_t T = sed_plan_num_frames(pl, L);
   if (T < 0) return (int)T;
@@ -1588,6 +1603,9 @@ static int front_forward(const sed_plan* pl, const void* pcm, int64_t B, int64_t
   p.aff_stride = pl->im.aff_stride;
   p.seg_off = seg_off;
   p.seg_len = seg_len;
+  p.seg_own = seg_own ? 1 : 0;
+  p.own_sub = c.center ? 0 : (c.win_align == SED_WIN_LEFT ? c.win_length : c.n_fft);
+  p.own_min = c.center ? (c.pad_mode == SED_PAD_REFLECT ? c.n_fft / 2 + 1 : 1) : p.own_sub;
   // (segments start anywhere: the kernel takes the LDS-DMA path for those that start on a 16-byte boundary)
   p.dma = (c.pcm_kind == SED_PCM_F32) && ((uintptr_t)pcm % 16 == 0) && (seg_off || pcm_stride % 4 == 0) && (c.hop % 4 == 0) ? 1 : 0;  // n_fft/2: a multiple of 4
   if (SED_SKIP(2048)) p.dma = 0;  // experiment: register-staged spans for fp32 too
@@ -1625,6 +1643,14 @@ extern "C" int sed_logmel_forward_segments(const sed_plan* pl, const void* pcm, 
   if (!seg_off || !seg_len) return SED_ERR_BAD_ARG;
   if (pl && (pl->cfg.tail_min_samples > 0 || pl->cfg.remove_dc || pl->cfg.preemphasis > 0.0f)) return SED_ERR_BAD_ARG;
   return front_forward<false>(pl, pcm, n_segments, L, L, out, out_stride_b, stream, seg_off, seg_len);
+}
+
+extern "C" int sed_logmel_forward_segments_own(const sed_plan* pl, const void* pcm, const int64_t* seg_off,
+                                               const int32_t* seg_len, int64_t n_segments, int64_t L, float* out,
+                                               int64_t out_stride_b, void* stream) {
+  if (!seg_off || !seg_len) return SED_ERR_BAD_ARG;
+  if (pl && (pl->cfg.tail_min_samples > 0 || pl->cfg.remove_dc || pl->cfg.preemphasis > 0.0f)) return SED_ERR_BAD_ARG;
+  return front_forward<false>(pl, pcm, n_segments, L, L, out, out_stride_b, stream, seg_off, seg_len, true);
 }
 
 extern "C" int sed_spectrogram_forward(const sed_plan* pl, const void* pcm, int64_t B, int64_t L, int64_t pcm_stride,

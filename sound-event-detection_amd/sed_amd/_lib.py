@@ -63,6 +63,7 @@ SIGNATURES = {
     "sed_plan_set_affine": (C.c_int, [_vp, _vp, _vp]),
     "sed_logmel_forward": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp]),
     "sed_logmel_forward_segments": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp]),
+    "sed_logmel_forward_segments_own": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp]),
     "sed_spectrogram_forward": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp]),
     "sed_mel_from_spectrogram": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "sed_db_normalize": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _vp]),
@@ -77,6 +78,7 @@ SIGNATURES = {
     "sed_threshold_merge_records": (C.c_int, [_vp, _i64, _i64, _i64, _f32, _i32, _vp, _i32, _f64, _i32, _vp, _i32, _vp]),
     "sed_pack_events": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _i32, _vp]),
     "sed_htsat_wav2img": (C.c_int, [_vp, _i64, _i64, _i64, _i64, _i32, _vp, _vp]),
+    "sed_htsat_wav2img_ragged": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp, _vp]),
     "sed_htsat_repeat2img": (C.c_int, [_vp, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _vp, _vp]),
     "sed_framewise_expand": (C.c_int, [_vp, _i64, _i64, _i64, _i32, _i64, _vp, _vp]),
     "sed_resampler_create": (C.c_int, [_i32, _i32, C.POINTER(_vp)]),

@@ -511,12 +511,19 @@ class LogMelFrontend(_PlanHolder):
         return out
 
     @torch.no_grad()
-    def forward_segments(self, pcm: torch.Tensor, seg_off, seg_len, n_samples: int):
+    def forward_segments(self, pcm: torch.Tensor, seg_off, seg_len, n_samples: int, own_edges: bool = False):
         """Log-mel of segments of a resident PCM buffer (the hand-off of handoff.logmel_of_events): clip e is the seg_len[e]
         samples from ELEMENT seg_off[e] of pcm's storage on, zero-padded to n_samples.  seg_off / seg_len: integer sequences
         or arrays on the host (checked against the buffer, clamped to n_samples and uploaded in one asynchronous copy), or
         int64 / int32 tensors already on the device (taken as they are).  Returns (log-mel in the module's layout, lengths (E,)
-        int32 on the device = the sample counts before clamping, for host arrays)."""
+        int32 on the device = the sample counts before clamping, for host arrays).
+
+        own_edges=True frames every segment as a recording of its own length, as the reference's second stage sees an event
+        file loaded alone (src/models/htsat/data.py:138-146, batch_size = 1 at src/models/htsat/classification.py:55-59): the
+        STFT's padding rule applies at the segment's own end and the segment has its own number of frames.  Returns
+        (log-mel, lengths, frames): frames (E,) int32 on the device, rows [0, frames[e]) of clip e hold its log-mel (the
+        values the front-end gives for those samples alone) and the rows behind them are zero.  A segment too short for one
+        frame has frames[e] = 0."""
         _require_cuda(pcm, "LogMelFrontend.forward_segments")
         want = torch.int16 if self.cfg.pcm_kind == L.PCM_I16 else torch.float32
         if pcm.dtype != want:
@@ -552,17 +559,34 @@ class LogMelFrontend(_PlanHolder):
             d_stage = stage.to(pcm.device, non_blocking=True)
             d_off, d_len = d_stage[:8 * E].view(torch.int64), d_stage[8 * E:12 * E].view(torch.int32)
             lengths = d_stage[12 * E:16 * E].view(torch.int32)
-        out = torch.empty((E, T, self.cfg.n_mels), dtype=torch.float32, device=pcm.device)
+        if own_edges:
+            out = torch.zeros((E, T, self.cfg.n_mels), dtype=torch.float32, device=pcm.device)
+            entry, name = L.lib.sed_logmel_forward_segments_own, "sed_logmel_forward_segments_own"
+        else:
+            out = torch.empty((E, T, self.cfg.n_mels), dtype=torch.float32, device=pcm.device)
+            entry, name = L.lib.sed_logmel_forward_segments, "sed_logmel_forward_segments"
         if E and T:
             with torch.cuda.device(pcm.device):
-                L.check(L.lib.sed_logmel_forward_segments(plan.ptr, pcm.data_ptr(), d_off.data_ptr(), d_len.data_ptr(), E,
-                                                          n_samples, out.data_ptr(), T * self.cfg.n_mels,
-                                                          L.stream_ptr(pcm.device)), "sed_logmel_forward_segments")
+                L.check(entry(plan.ptr, pcm.data_ptr(), d_off.data_ptr(), d_len.data_ptr(), E, n_samples, out.data_ptr(),
+                              T * self.cfg.n_mels, L.stream_ptr(pcm.device)), name)
         if self.layout == "b1tm":
-            return out[:, None, :, :], lengths
-        if self.layout == "bmt":
-            return out.transpose(1, 2), lengths
+            out = out[:, None, :, :]
+        elif self.layout == "bmt":
+            out = out.transpose(1, 2)
+        if own_edges:
+            return out, lengths, self._own_frames(d_len, n_samples)
         return out, lengths
+
+    def _own_frames(self, d_len: torch.Tensor, n_samples: int) -> torch.Tensor:
+        """Frames of segments framed as recordings of their own (the kernel's rule): int32 on d_len's device."""
+        c = self.cfg
+        if c.center:
+            sub, least = 0, (c.n_fft // 2 + 1 if c.pad_mode == L.PAD_REFLECT else 1)
+        else:
+            sub = c.win_length if c.win_align == L.WIN_LEFT else c.n_fft
+            least = sub
+        n = d_len.clamp(max=n_samples)
+        return torch.where(n >= least, 1 + (n - sub) // c.hop, torch.zeros_like(n)).to(torch.int32)
 
 
 class _LogmelPassthrough(nn.Module):
@@ -686,10 +710,14 @@ def wav2fbank(waveform, sr, melbins=128, target_length=1024, fshift=10, norm_mea
     return fb
 
 
-def reshape_wav2img(x: torch.Tensor, spec_size: int = 256, freq_ratio: int = None) -> torch.Tensor:
+def reshape_wav2img(x: torch.Tensor, spec_size: int = 256, freq_ratio: int = None, frames: torch.Tensor = None) -> torch.Tensor:
     """HTSAT_Swin_Transformer.reshape_wav2img (external/hts_audio_transformer/model/htsat.py:729-744):
     x (B, 1, T, F) log-mel -> (B, 1, spec_size, spec_size) for F == spec_size // freq_ratio (freq_ratio defaults to
-    spec_size // F as at htsat.py:444).  T < spec_size*freq_ratio is interpolated (bicubic, align_corners=True)."""
+    spec_size // F as at htsat.py:444).  T < spec_size*freq_ratio is interpolated (bicubic, align_corners=True).
+
+    frames (B,) int32 on the device: clip b holds frames[b] <= T rows of its own (events of different lengths in one batch,
+    LogMelFrontend.forward_segments(..., own_edges=True)), and each clip is stretched to the image from its own rows, as the
+    reference does for an event file fed alone.  A clip with no frame gives zeros."""
     _require_cuda(x, "reshape_wav2img")
     if x.dim() != 4 or x.shape[1] != 1:
         raise RuntimeError(f"expected a (batch, 1, time, mel) tensor, got shape {tuple(x.shape)}")
@@ -703,8 +731,15 @@ def reshape_wav2img(x: torch.Tensor, spec_size: int = 256, freq_ratio: int = Non
     x = x.to(torch.float32).contiguous()
     img = torch.empty((B, 1, freq_ratio * F, target_T // freq_ratio), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        L.check(L.lib.sed_htsat_wav2img(x.data_ptr(), B, T, F, target_T, freq_ratio, img.data_ptr(),
-                                        L.stream_ptr(x.device)), "sed_htsat_wav2img")
+        if frames is None:
+            L.check(L.lib.sed_htsat_wav2img(x.data_ptr(), B, T, F, target_T, freq_ratio, img.data_ptr(),
+                                            L.stream_ptr(x.device)), "sed_htsat_wav2img")
+        else:
+            if not (torch.is_tensor(frames) and frames.device == x.device and frames.dtype == torch.int32 and
+                    frames.shape == (B,) and frames.is_contiguous()):
+                raise TypeError("frames: a contiguous int32 tensor with one entry per clip on x's device")
+            L.check(L.lib.sed_htsat_wav2img_ragged(x.data_ptr(), frames.data_ptr(), B, T, F, target_T, freq_ratio,
+                                                   img.data_ptr(), L.stream_ptr(x.device)), "sed_htsat_wav2img_ragged")
     return img
 
 

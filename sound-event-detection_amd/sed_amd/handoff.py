@@ -78,7 +78,8 @@ def _event_ranges(events, sr, n):
     return idx, a, np.maximum(b - a, 0)
 
 
-def logmel_of_events(frontend, pcm: torch.Tensor, sr, events: Sequence[Tuple[int, float, float]], cap: int):
+def logmel_of_events(frontend, pcm: torch.Tensor, sr, events: Sequence[Tuple[int, float, float]], cap: int,
+                     per_file: bool = False):
     """The classifier front-end on the detected events WITHOUT the cut in between: the fused log-mel kernel reads every
     event's samples straight out of the resident recordings (src/utils/cut_audio.py:13-53 + main.py:123-127 write the events
     as files for stage 2; external/hts_audio_transformer/model/htsat.py:763-764 is the front-end they feed).
@@ -87,7 +88,15 @@ def logmel_of_events(frontend, pcm: torch.Tensor, sr, events: Sequence[Tuple[int
     (longer events are truncated, shorter ones zero-padded, as cut_events(..., cap=cap) does).  frontend: a LogMelFrontend
     whose configuration takes pcm's sample type (for int16 recordings: pcm_kind=1 and the divisor of the hand-off).
     Returns (log-mel of the E events in the frontend's layout, lengths (E,) int32 on the device): the same values, bit for
-    bit, as frontend(cut_events(pcm, sr, events, cap)[0]), with neither the (E, cap) batch nor its kernel."""
+    bit, as frontend(cut_events(pcm, sr, events, cap)[0]), with neither the (E, cap) batch nor its kernel.
+
+    per_file=True gives every event the log-mel of a file of its own, which is what the reference's second stage computes:
+    it loads each written event at its natural length and feeds it alone (src/models/htsat/data.py:138-146, batch_size = 1
+    at src/models/htsat/classification.py:55-59), so the reflect padding of the STFT mirrors the event's own last samples
+    and the event has 1 + len // hop frames of its own.  Returns (log-mel, lengths, frames): rows [0, frames[e]) of event e
+    equal frontend(event's samples alone) bit for bit, the rows behind them are zero; frames (E,) int32 on the device goes to
+    reshape_wav2img(..., frames=frames), which stretches every event to the image from its own rows.  Events too short for
+    the front-end (the reference's STFT raises on them) have frames[e] = 0."""
     from . import frontend as F
     if not isinstance(frontend, F.LogMelFrontend):
         raise TypeError("logmel_of_events needs a sed_amd.LogMelFrontend")
@@ -104,7 +113,7 @@ def logmel_of_events(frontend, pcm: torch.Tensor, sr, events: Sequence[Tuple[int
     idx, a, length = _event_ranges(events, sr, n)
     if len(idx) and (idx.min() < 0 or idx.max() >= S):
         raise ValueError("event names a stream outside the batch")
-    return frontend.forward_segments(pcm, idx * max(pcm.stride(0), n) + a, length, cap)
+    return frontend.forward_segments(pcm, idx * max(pcm.stride(0), n) + a, length, cap, own_edges=bool(per_file))
 
 
 def cut_events_from_audio(pcm: torch.Tensor, sr, filenames: Sequence[str], events_list: Dict[str, List[dict]],

@@ -111,7 +111,7 @@ def one_case(rng, case, dev):
             raise
         # segment mode: events out of the resident batch, against cut + front-end
         extra = ""
-        if center and n > 3 * n_fft:
+        if n > 3 * n_fft:
             fe_btm = sed_amd.LogMelFrontend.from_torchlibrosa(sp, lm)
             events = []
             for _ in range(int(rng.integers(1, 7))):
@@ -123,6 +123,19 @@ def one_case(rng, case, dev):
             got, glen = sed_amd.logmel_of_events(fe_btm, xt, sr, events, cap)
             assert torch.equal(glen.cpu(), lengths.cpu()), "segment lengths"
             assert torch.equal(got, want), f"segment mode differs from cut + front-end (max {float(torch.max(torch.abs(got - want))):.3e})"
+            # every event framed as a file of its own: the front-end on the event's samples alone, bit for bit
+            events.append((0, 0.0, (lo - 1) / sr))                   # one sample too short for a frame
+            events.append((B - 1, 0.1, 0.1 + (lo + 0.5) / sr))       # the shortest that has one
+            own, olen, frames = sed_amd.logmel_of_events(fe_btm, xt, sr, events, cap, per_file=True)
+            for e, (s_, a, b) in enumerate(events):
+                piece = x[s_, int(a * sr):int(b * sr)][:cap]
+                least = (n_fft // 2 + 1 if pad_mode == "reflect" else 1) if center else n_fft   # (constant padding takes any length)
+                Te = (1 + len(piece) // hop if center else 1 + (len(piece) - n_fft) // hop) if len(piece) >= least else 0
+                assert int(frames[e]) == Te, f"own frames of event {e}: {int(frames[e])} for {Te}"
+                assert not own[e, :, Te:].any(), f"rows behind event {e}"
+                if Te:
+                    alone = fe_btm(torch.from_numpy(piece[None].copy()).to(dev))
+                    assert torch.equal(own[e, :, :Te], alone[0]), f"event {e} of {len(piece)} samples differs from the event alone"
             extra = f" seg{len(events)}"
         print(f"ok   {desc} rel {rel:.1e} near {near:.1e} deep {deep:.1e}{extra}", flush=True)
         return True

@@ -44,6 +44,16 @@ def main():
                 assert np.max(np.abs(got - want)) <= 2e-6 * np.max(np.abs(x)), f"wav2img {np.max(np.abs(got - want)):.3e}"
                 if T == target_T:
                     assert np.array_equal(got, want), "fold without interpolation"
+                # clips with frame counts of their own: every clip as the dense call on its own rows gives it, bit for bit
+                fr = rng.integers(0, T + 1, size=B).astype(np.int32)
+                fr[int(rng.integers(B))] = int(rng.choice([1, 2, T]))
+                rag = sed_amd.reshape_wav2img(xd, spec, ratio, frames=torch.from_numpy(fr).to(dev))
+                for b in range(B):
+                    if fr[b] == 0:
+                        assert not rag[b].any(), "clip without frames"
+                    else:
+                        alone = sed_amd.reshape_wav2img(xd[b:b + 1, :, :int(fr[b])].contiguous(), spec, ratio)
+                        assert torch.equal(rag[b:b + 1], alone), f"ragged clip {b} with {int(fr[b])} of {T} frames"
                 if ratio == 4 and spec <= target_T:       # the reference tiles the crop four times (htsat.py:758)
                     pos = int(rng.integers(0, target_T - spec + 1))
                     g2 = sed_amd.repeat_wat2img(xd, pos, spec, ratio).cpu().numpy()

@@ -178,3 +178,72 @@ def test_events_handed_to_the_audio_mamba_front_end():
     # without lengths the batch is what it looks like: clips of the padded length
     dense = sed_amd.wav2fbank(clips, sr, melbins=128, target_length=256)
     assert dense.shape == (len(events), 256, 128)
+
+
+def test_events_as_files_of_their_own_for_the_htsat_classifier():
+    """Stage 2 of the reference loads every written event at its natural length and feeds it alone
+    (src/models/htsat/data.py:138-146, batch_size = 1 at src/models/htsat/classification.py:55-59): the STFT mirrors the
+    event's own ends (htsat.py:763) and reshape_wav2img stretches the event's own 1 + len // hop frames to the image
+    (htsat.py:729-744).  logmel_of_events(per_file=True) + reshape_wav2img(frames=...) do that for a batch of events of
+    different lengths in two launches: compared event by event, bit for bit, with the front-end and the image kernel run on
+    that event alone, and with the CPU restatement on the event's samples."""
+    import sed_amd
+    dev = torch.device("cuda", 0)
+    sr = 44100
+    S, n = 3, 12 * sr
+    x = of.synth_batch(S, n, sr, first=77)
+    xd = torch.from_numpy(x).to(dev)
+    cfg = sed_amd.FrontendConfig.htsat(sample_rate=sr)
+    hop, half = cfg.hop, cfg.n_fft // 2
+    events = [(0, 0.5, 2.75), (1, 1.0, 1.0 + 513 / sr), (2, 0.0, 11.99), (1, 3.3, 4.0), (0, 11.0, 13.5), (2, 2.0, 2.0),
+              (1, 5.0, 5.0 + 512 / sr), (0, 0.25, 0.25 + 4 * hop / sr), (2, 6.000011, 6.9), (1, 0.0, 12.0), (0, 7.0, 7.01)]
+    # (513 samples: the shortest event the reflect padding takes; 512 and the empty one: none; one past the end of its file)
+    cap = 10 * sr                                                          # the 12 s event is cut to the classifier's clip
+    for layout in ("b1tm", "btm"):
+        fe = sed_amd.LogMelFrontend(cfg, layout=layout)
+        y, lengths, frames = sed_amd.logmel_of_events(fe, xd, sr, events, cap, per_file=True)
+        T = fe.num_frames(cap, dev)
+        y3 = y[:, 0] if layout == "b1tm" else y
+        assert y3.shape == (len(events), T, 64) and frames.dtype == torch.int32
+        for e, (s, a, b) in enumerate(events):
+            piece = x[s, int(a * sr):int(b * sr)]
+            assert int(lengths[e]) == len(piece)
+            piece = piece[:cap]
+            want_T = 1 + len(piece) // hop if len(piece) > half else 0
+            assert int(frames[e]) == want_T, e
+            assert not y3[e, want_T:].any(), e                             # nothing behind the event's own frames
+            if want_T == 0:
+                with pytest.raises((ValueError, RuntimeError)):            # as the reference's STFT refuses such a file
+                    fe(torch.from_numpy(piece[None].copy()).to(dev))
+                continue
+            alone = fe(torch.from_numpy(piece[None].copy()).to(dev))
+            alone3 = alone[:, 0] if layout == "b1tm" else alone
+            assert torch.equal(y3[e, :want_T], alone3[0]), (layout, e)
+    # against the restatement on the event's own samples, and the image of every event from its own frames
+    fe = sed_amd.LogMelFrontend(cfg)
+    y, lengths, frames = sed_amd.logmel_of_events(fe, xd, sr, events, cap, per_file=True)
+    img = sed_amd.reshape_wav2img(y, 512, 8, frames=frames)
+    assert img.shape == (len(events), 1, 512, 512)
+    yn = y.cpu().numpy()
+    for e, (s, a, b) in enumerate(events):
+        piece = x[s, int(a * sr):int(b * sr)][:cap]
+        Te = int(frames[e])
+        if Te == 0:
+            assert not img[e].any()
+            continue
+        gold = of.htsat_logmel(piece[None], sr=sr, mode="gold")
+        assert gold.shape == (1, 1, Te, 64)
+        near = gold[0, 0] >= gold[0, 0].max(-1, keepdims=True) - 60.0
+        assert np.max(np.abs(yn[e, 0, :Te] - gold[0, 0])[near]) < 1e-3, e
+        alone = sed_amd.reshape_wav2img(y[e:e + 1, :, :Te].contiguous(), 512, 8)
+        assert torch.equal(img[e:e + 1], alone), e
+        want = of.htsat_reshape_wav2img(yn[e:e + 1, :, :Te], 512, 8)
+        assert np.max(np.abs(img[e:e + 1].cpu().numpy() - want)) <= 2e-6 * np.max(np.abs(yn[e, 0, :Te])), e
+    # the zero-padded-batch reading stays the default, and differs where the padding rule matters
+    y0, _ = sed_amd.logmel_of_events(fe, xd, sr, events, cap)
+    assert not torch.equal(y0[0], y[0])
+    with pytest.raises(TypeError):
+        sed_amd.reshape_wav2img(y, 512, 8, frames=frames.cpu())
+    # Kaldi-framed and YAMNet plans have no segment mode
+    with pytest.raises(ValueError):
+        sed_amd.logmel_of_events(sed_amd.LogMelFrontend(sed_amd.FrontendConfig.yamnet()), xd, 16000, events[:2], 48000, per_file=True)
