@@ -50,3 +50,17 @@ for mod in (0, 1, 2):
         clips, _ = sed_amd.cut_events(x, sr, ev, cap=cap)
         same = torch.equal(sed_amd.logmel_of_events(fe, x, sr, ev, cap)[0], fe(clips))
         print(f"segments start = {mod} mod 4 samples, {secs} s of {cap / sr} s rows: {t:.1f} us with host prep and upload, {tk:.1f} us kernel alone, same bits {same}")
+
+# every event framed as a file of its own (padding rule at its own end, its own frames; the output is cleared first), and the
+# images stretched from each event's own rows
+for secs in (3.0, 1.5, 0.5):
+    ev = events(0, secs)
+    idx, a, length = sed_amd.handoff._event_ranges(ev, sr, n)
+    d_off = torch.from_numpy(idx * n + a).to(dev)
+    d_len = torch.from_numpy(np.minimum(length, cap).astype(np.int32)).to(dev)
+    tk = timed(lambda: fe.forward_segments(x, d_off, d_len, cap, own_edges=True))
+    fe4 = sed_amd.LogMelFrontend(sed_amd.FrontendConfig.htsat())
+    y, _, frames = fe4.forward_segments(x, d_off, d_len, cap, own_edges=True)
+    ti = timed(lambda: sed_amd.reshape_wav2img(y, 256, 4, frames=frames))
+    td = timed(lambda: sed_amd.reshape_wav2img(y, 256, 4))
+    print(f"events as files of their own, {secs} s: {tk:.1f} us (clear + kernel + frame counts), image from own rows {ti:.1f} us (dense image {td:.1f} us)")
