@@ -157,9 +157,9 @@ int sed_logmel_forward_segments(const sed_plan* plan, const void* pcm, const int
  * src/models/htsat/classification.py:55-59), so the padding rule of the STFT applies at the event's own end
  * (htsat.py:763, center=True, pad_mode='reflect') and the event has its own number of frames.  Segment e, n = seg_len[e]
  * samples (clamped to L), gets frames_e = 1 + n / hop frames (center) or 1 + (n - frame) / hop (not centred), and rows
- * [0, frames_e) of out[e] equal sed_logmel_forward on the n samples alone, bit for bit.  Rows from frames_e on are NOT
- * WRITTEN (clear the buffer beforehand if they are read).  A segment too short for the plan (n <= n_fft/2 under reflect
- * padding, n < frame when not centred, n = 0) gets no row.  L is only the row capacity: out is
+ * [0, frames_e) of out[e] equal sed_logmel_forward on the n samples alone, bit for bit.  Rows from frames_e on are
+ * written as zeros.  A segment too short for the plan (n <= n_fft/2 under reflect padding, n < frame when not
+ * centred, n = 0) has frames_e = 0.  L is only the row capacity: out is
  * [n_segments][sed_plan_num_frames(plan, L)][n_mels].  Arguments and errors otherwise as sed_logmel_forward_segments. */
 int sed_logmel_forward_segments_own(const sed_plan* plan, const void* pcm, const int64_t* seg_off, const int32_t* seg_len,
                                     int64_t n_segments, int64_t L, float* out, int64_t out_stride_b, void* stream);

@@ -51,7 +51,7 @@ for mod in (0, 1, 2):
         same = torch.equal(sed_amd.logmel_of_events(fe, x, sr, ev, cap)[0], fe(clips))
         print(f"segments start = {mod} mod 4 samples, {secs} s of {cap / sr} s rows: {t:.1f} us with host prep and upload, {tk:.1f} us kernel alone, same bits {same}")
 
-# every event framed as a file of its own (padding rule at its own end, its own frames; the output is cleared first), and the
+# every event framed as a file of its own (padding rule at its own end, its own frames, zeros behind them; segment tables on the device, so the frame counts are a few small launches), and the
 # images stretched from each event's own rows
 for secs in (3.0, 1.5, 0.5):
     ev = events(0, secs)
@@ -63,4 +63,4 @@ for secs in (3.0, 1.5, 0.5):
     y, _, frames = fe4.forward_segments(x, d_off, d_len, cap, own_edges=True)
     ti = timed(lambda: sed_amd.reshape_wav2img(y, 256, 4, frames=frames))
     td = timed(lambda: sed_amd.reshape_wav2img(y, 256, 4))
-    print(f"events as files of their own, {secs} s: {tk:.1f} us (clear + kernel + frame counts), image from own rows {ti:.1f} us (dense image {td:.1f} us)")
+    print(f"events as files of their own, {secs} s: {tk:.1f} us (kernel + frame counts), image from own rows {ti:.1f} us (dense image {td:.1f} us)")

@@ -531,9 +531,15 @@ __device__ __forceinline__ v4 mel_gather_finish(const FrontParams& p, const floa
 }
 
 // Store of one gather round: 16 bytes per lane, 1 KB contiguous per wavefront (frames are n_mels floats apart).
-__device__ __forceinline__ void mel_store(const FrontParams& p, float* dst, v4 val, int r, int nvalid, int lane) {
+// ZERO_TAIL (segment kernels): rows [nvalid, nrows) are written as zeros (the rows behind a segment's own frames).
+template <bool ZERO_TAIL = false>
+__device__ __forceinline__ void mel_store(const FrontParams& p, float* dst, v4 val, int r, int nvalid, int lane, int nrows = 0) {
   asm volatile("" : "+v"(lane));  // the per-lane output offset is recomputed here instead of living across the loop
   const int j = lane & 3, m0 = 4 * (16 * r + (lane >> 2));
+  if constexpr (ZERO_TAIL) {
+    if (j >= nvalid) val = v4{0.0f, 0.0f, 0.0f, 0.0f};
+    nvalid = nrows;
+  }
   if (j < nvalid && m0 < p.n_mels) {
     float* o = dst + j * p.n_mels + m0;
     if (p.out_vec) {
@@ -622,7 +628,7 @@ stft_mel_kernel(const FrontParams p) {
     bool staged = false, held = false;
     v4 hval[kGroups][2];
     float* hdst = nullptr;
-    int hvalid = 0;
+    int hvalid = 0, hrows = 0;  // rows of the held group with values / rows written (segments: zeros behind the values)
     // Segments: the log-mel values of a frame made of zeros only (the padding behind a short segment), through the very
     // expressions of the gather (sum of zero partial sums, log, affine), so that groups of such frames can skip the transform.
     v4 zc[2] = {v4{0.0f, 0.0f, 0.0f, 0.0f}, v4{0.0f, 0.0f, 0.0f, 0.0f}};
@@ -665,14 +671,15 @@ stft_mel_kernel(const FrontParams p) {
           if (held) {
             static_for<0, kGroups>([&](auto Gf) {
               constexpr int g = decltype(Gf)::value;
-              mel_store(p, hdst + 4 * g * p.n_mels, hval[g][0], 0, hvalid - 4 * g, lane);
-              if (mel_two_rounds<Mel>(p)) mel_store(p, hdst + 4 * g * p.n_mels, hval[g][1], 1, hvalid - 4 * g, lane);
+              mel_store<SEG>(p, hdst + 4 * g * p.n_mels, hval[g][0], 0, hvalid - 4 * g, lane, hrows - 4 * g);
+              if (mel_two_rounds<Mel>(p)) mel_store<SEG>(p, hdst + 4 * g * p.n_mels, hval[g][1], 1, hvalid - 4 * g, lane, hrows - 4 * g);
             });
           }
           static_for<0, kGroups>([&](auto Gf) { hval[decltype(Gf)::value][0] = zc[0]; hval[decltype(Gf)::value][1] = zc[1]; });
-          held = !p.seg_own;  // (rows behind a segment's own frames are not written)
+          held = true;
           hdst = p.out + (int64_t)b * p.out_stride_b + (int64_t)f0 * p.n_mels;
-          hvalid = min(G::FPW, p.T - f0);
+          hrows = min(G::FPW, p.T - f0);
+          hvalid = p.seg_own ? 0 : hrows;  // (the rows behind a segment's own frames are zero)
           gi = group_of(__builtin_amdgcn_readfirstlane(taken));
           if (gi >= g_end) break;
           b = gi / p.groups_per_clip;
@@ -712,8 +719,8 @@ stft_mel_kernel(const FrontParams p) {
         if (held) {
           static_for<0, kGroups>([&](auto Gf) {
             constexpr int g = decltype(Gf)::value;
-            mel_store(p, hdst + 4 * g * p.n_mels, hval[g][0], 0, hvalid - 4 * g, lane);
-            if (mel_two_rounds<Mel>(p)) mel_store(p, hdst + 4 * g * p.n_mels, hval[g][1], 1, hvalid - 4 * g, lane);
+            mel_store<SEG>(p, hdst + 4 * g * p.n_mels, hval[g][0], 0, hvalid - 4 * g, lane, hrows - 4 * g);
+            if (mel_two_rounds<Mel>(p)) mel_store<SEG>(p, hdst + 4 * g * p.n_mels, hval[g][1], 1, hvalid - 4 * g, lane, hrows - 4 * g);
           });
         }
       }
@@ -872,6 +879,7 @@ stft_mel_kernel(const FrontParams p) {
         held = !SED_SKIP(64);
         hdst = p.out + (int64_t)b * p.out_stride_b + (int64_t)f0 * p.n_mels;
         hvalid = nvalid;
+        hrows = min(G::FPW, p.T - f0);
       }
       wave_phase_fence();
       SED_STAMP(6)
@@ -883,8 +891,8 @@ stft_mel_kernel(const FrontParams p) {
       if (held) {
         static_for<0, kGroups>([&](auto Gf) {
           constexpr int g = decltype(Gf)::value;
-          mel_store(p, hdst + 4 * g * p.n_mels, hval[g][0], 0, hvalid - 4 * g, lane);
-          if (mel_two_rounds<Mel>(p)) mel_store(p, hdst + 4 * g * p.n_mels, hval[g][1], 1, hvalid - 4 * g, lane);
+          mel_store<SEG>(p, hdst + 4 * g * p.n_mels, hval[g][0], 0, hvalid - 4 * g, lane, hrows - 4 * g);
+          if (mel_two_rounds<Mel>(p)) mel_store<SEG>(p, hdst + 4 * g * p.n_mels, hval[g][1], 1, hvalid - 4 * g, lane, hrows - 4 * g);
         });
       }
     }

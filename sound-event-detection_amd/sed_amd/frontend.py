@@ -540,6 +540,7 @@ class LogMelFrontend(_PlanHolder):
                     seg_off.dim() == 1 and seg_off.shape == seg_len.shape and seg_off.is_contiguous() and seg_len.is_contiguous()):
                 raise TypeError("device-side segments: contiguous int64 offsets and int32 lengths of one shape on pcm's device")
             d_off, d_len, lengths, E = seg_off, seg_len, seg_len, seg_off.shape[0]
+            frames = self._own_frames(d_len.clamp(max=n_samples)) if own_edges else None
         else:
             off = np.ascontiguousarray(seg_off, dtype=np.int64).reshape(-1)
             full = np.ascontiguousarray(seg_len, dtype=np.int64).reshape(-1)
@@ -550,20 +551,22 @@ class LogMelFrontend(_PlanHolder):
             extent = (pcm.shape[0] - 1) * pcm.stride(0) + pcm.shape[1] if pcm.dim() == 2 and pcm.shape[0] > 0 else pcm.numel()
             if E and (off.min() < 0 or full.min() < 0 or (off + full).max() > extent):
                 raise ValueError("a segment lies outside the PCM buffer")
-            # one asynchronous upload from pinned memory: [offsets int64 | clamped lengths int32 | full lengths int32]
-            stage = torch.empty(16 * max(E, 1), dtype=torch.uint8, pin_memory=True)
+            # one asynchronous upload from pinned memory: [offsets int64 | clamped lengths int32 | full lengths int32 | own frames int32]
+            stage = torch.empty(20 * max(E, 1), dtype=torch.uint8, pin_memory=True)
             host = stage.numpy()
+            clamped = np.minimum(full, n_samples)
             host[:8 * E] = off.view(np.uint8)
-            host[8 * E:12 * E] = np.minimum(full, n_samples).astype(np.int32).view(np.uint8)
+            host[8 * E:12 * E] = clamped.astype(np.int32).view(np.uint8)
             host[12 * E:16 * E] = np.minimum(full, 2 ** 31 - 1).astype(np.int32).view(np.uint8)
+            host[16 * E:20 * E] = self._own_frames(clamped).astype(np.int32).view(np.uint8)
             d_stage = stage.to(pcm.device, non_blocking=True)
             d_off, d_len = d_stage[:8 * E].view(torch.int64), d_stage[8 * E:12 * E].view(torch.int32)
             lengths = d_stage[12 * E:16 * E].view(torch.int32)
+            frames = d_stage[16 * E:20 * E].view(torch.int32)
+        out = torch.empty((E, T, self.cfg.n_mels), dtype=torch.float32, device=pcm.device)
         if own_edges:
-            out = torch.zeros((E, T, self.cfg.n_mels), dtype=torch.float32, device=pcm.device)
             entry, name = L.lib.sed_logmel_forward_segments_own, "sed_logmel_forward_segments_own"
         else:
-            out = torch.empty((E, T, self.cfg.n_mels), dtype=torch.float32, device=pcm.device)
             entry, name = L.lib.sed_logmel_forward_segments, "sed_logmel_forward_segments"
         if E and T:
             with torch.cuda.device(pcm.device):
@@ -574,19 +577,21 @@ class LogMelFrontend(_PlanHolder):
         elif self.layout == "bmt":
             out = out.transpose(1, 2)
         if own_edges:
-            return out, lengths, self._own_frames(d_len, n_samples)
+            return out, lengths, frames
         return out, lengths
 
-    def _own_frames(self, d_len: torch.Tensor, n_samples: int) -> torch.Tensor:
-        """Frames of segments framed as recordings of their own (the kernel's rule): int32 on d_len's device."""
+    def _own_frames(self, n):
+        """Frames of segments of n samples framed as recordings of their own (the kernel's rule); n: a numpy array or a
+        tensor of sample counts already clamped to the row, the result is of the same kind."""
         c = self.cfg
         if c.center:
             sub, least = 0, (c.n_fft // 2 + 1 if c.pad_mode == L.PAD_REFLECT else 1)
         else:
             sub = c.win_length if c.win_align == L.WIN_LEFT else c.n_fft
             least = sub
-        n = d_len.clamp(max=n_samples)
-        return torch.where(n >= least, 1 + (n - sub) // c.hop, torch.zeros_like(n)).to(torch.int32)
+        if torch.is_tensor(n):
+            return torch.where(n >= least, 1 + (n - sub) // c.hop, torch.zeros_like(n)).to(torch.int32)
+        return np.where(n >= least, 1 + (n - sub) // c.hop, 0)
 
 
 class _LogmelPassthrough(nn.Module):
