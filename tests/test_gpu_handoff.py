@@ -247,3 +247,73 @@ def test_events_as_files_of_their_own_for_the_htsat_classifier():
     # Kaldi-framed and YAMNet plans have no segment mode
     with pytest.raises(ValueError):
         sed_amd.logmel_of_events(sed_amd.LogMelFrontend(sed_amd.FrontendConfig.yamnet()), xd, 16000, events[:2], 48000, per_file=True)
+
+
+def test_two_stage_chain_as_main_runs_it():
+    """main.py's two-stage flow end to end on resident audio, with stand-ins for the two networks: recordings at 44.1 kHz
+    -> 16 kHz (librosa.load(sr=16000), yamnet_train.py:46) -> YAMNet patches -> [detector stand-in: patch energy] ->
+    detect_onsets_offsets (yamnet_train.py:55-71) -> events handed over as files of their own (cut_audio.py:13-53,
+    htsat/data.py:138-146) -> HTS-AT log-mel + reshape_wav2img (htsat.py:763-764, 729-744) -> [classifier stand-in:
+    strongest mel band] -> labelled events -> calculate_metrics (main.py:29-48).  The same chain is walked on the CPU with
+    the restatements, fed with the same probabilities: events, labels and metrics must come out the same."""
+    import sed_amd
+    from oracle import decode as od, metrics as om
+    dev = torch.device("cuda", 0)
+    sr, S, secs = 44100, 4, 20
+    n = sr * secs
+    tones = {"cough": 400.0, "dog_bark": 900.0, "gun_shot": 1800.0, "siren": 3500.0, "car_horn": 7000.0}
+    classes = list(tones)
+    rng = np.random.default_rng(12)
+    x = (0.002 * rng.standard_normal((S, n))).astype(np.float32)
+    names, gt = [f"rec_{s}.wav" for s in range(S)], {}
+    t = np.arange(n) / sr
+    for s, name in enumerate(names):
+        gt[name] = []
+        for k, start in enumerate((3.0 + 0.7 * s, 11.5 + 0.4 * s)):
+            label = classes[(2 * s + k) % 5]
+            dur = 2.4 + 0.48 * ((s + k) % 3)
+            m = (t >= start) & (t < start + dur)
+            x[s, m] += (0.3 * np.sin(2 * np.pi * tones[label] * t[m])).astype(np.float32)
+            gt[name].append({"file": name, "event_onset": start, "event_offset": start + dur, "event_label": label})
+    pcm = torch.from_numpy(x).to(dev)
+    # stage 1: detector features and decode
+    x16 = sed_amd.resample(pcm, orig_sr=sr, target_sr=16000)
+    _, patches = sed_amd.yamnet_log_mel(x16)
+    assert patches.shape[:2] == (S, 41)                                    # N_FRAMES of single_stage_yamnet_frame.py:20
+    probs = torch.sigmoid(2.0 * (patches.amax(dim=3).mean(dim=2) - 1.5)).cpu().numpy().astype(np.float32)
+    got = sed_amd.detect_onsets_offsets_batch(probs, 0.5, 0.48, True)
+    events = []
+    for s in range(S):
+        on, off = od.detect_onsets_offsets(probs[s], 0.5, 0.48, True)
+        assert np.array_equal(np.asarray(got[s][0]), on) and np.array_equal(np.asarray(got[s][1]), off)
+        assert len(on) == len(off) == 2, (s, on, off)
+        events += [(s, float(a), float(b)) for a, b in zip(on, off)]
+    # stage 2: every event as a file of its own through the classifier's front-end
+    cfg = sed_amd.FrontendConfig.htsat(sample_rate=sr)
+    fe = sed_amd.LogMelFrontend(cfg)
+    y, lengths, frames = sed_amd.logmel_of_events(fe, pcm, sr, events, 20 * sr, per_file=True)
+    img = sed_amd.reshape_wav2img(y, 512, 8, frames=frames)
+    centres = of.mel_to_hz_slaney(np.linspace(of.hz_to_mel_slaney(50.0), of.hz_to_mel_slaney(14000.0), 66))[1:-1]
+    class_bin = np.array([int(np.argmin(np.abs(centres - f))) for f in tones.values()])
+
+    def label_of(image):                                                   # (512, 512): 8 bands of 64 mel rows
+        band = image.reshape(8, 64, 512).mean(axis=(0, 2))
+        return classes[int(np.argmin(np.abs(class_bin - int(np.argmax(band)))))]
+
+    pred = {name: [] for name in names}
+    for e, (s, a, b) in enumerate(events):
+        piece = x[s, int(a * sr):int(b * sr)]
+        assert int(lengths[e]) == len(piece) and int(frames[e]) == 1 + len(piece) // cfg.hop
+        gold = of.htsat_reshape_wav2img(of.htsat_logmel(piece[None], sr=sr, mode="gold").astype(np.float32), 512, 8)
+        mine = img[e, 0].cpu().numpy()
+        assert label_of(mine) == label_of(gold[0, 0]), e
+        loud = gold[0, 0] > gold.max() - 40.0
+        assert np.max(np.abs(mine - gold[0, 0])[loud]) < 2e-3, e
+        pred[names[s]].append({"file": names[s], "event_onset": a, "event_offset": b, "event_label": label_of(mine)})
+    ev, seg = sed_amd.calculate_metrics(pred, gt, time_resolution=1.0, t_collar=1.0, classes=classes, verbose=False)
+    oe, osg = om.EventBasedMetrics(classes, t_collar=1.0), om.SegmentBasedMetrics(classes, 1.0)
+    for name in names:
+        oe.evaluate(gt[name], pred[name]); osg.evaluate(gt[name], pred[name])
+    assert ev.results()["overall"] == oe.results_overall_metrics() and seg.results()["overall"] == osg.results_overall_metrics()
+    assert ev.overall["Nref"] == 2 * S and ev.overall["Nsubs"] == 0 and seg.overall["S"] == 0      # every label right
+    assert ev.overall["Ntp"] == 2 * S and seg.results()["overall"]["f_measure"]["f_measure"] > 0.7
