@@ -239,6 +239,16 @@ def test_events_as_files_of_their_own_for_the_htsat_classifier():
         assert torch.equal(img[e:e + 1], alone), e
         want = of.htsat_reshape_wav2img(yn[e:e + 1, :, :Te], 512, 8)
         assert np.max(np.abs(img[e:e + 1].cpu().numpy() - want)) <= 2e-6 * np.max(np.abs(yn[e, 0, :Te])), e
+    # int16 recordings (the samples as the wav files hold them): the same, through the plan's own conversion
+    xi = torch.from_numpy(np.random.default_rng(5).integers(-20000, 20000, (S, n), dtype=np.int16)).to(dev)
+    fe16 = sed_amd.LogMelFrontend(sed_amd.FrontendConfig.htsat(sample_rate=sr, pcm_kind=1, pcm_divisor=32768.0), layout="btm")
+    y16, _, fr16 = sed_amd.logmel_of_events(fe16, xi, sr, events, cap, per_file=True)
+    assert torch.equal(fr16, frames)
+    for e, (s, a, b) in enumerate(events):
+        Te = int(fr16[e])
+        assert not y16[e, Te:].any()
+        if Te:
+            assert torch.equal(y16[e, :Te], fe16(xi[s:s + 1, int(a * sr):int(b * sr)][:, :cap].contiguous())[0]), e
     # the zero-padded-batch reading stays the default, and differs where the padding rule matters
     y0, _ = sed_amd.logmel_of_events(fe, xd, sr, events, cap)
     assert not torch.equal(y0[0], y[0])
