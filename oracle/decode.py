@@ -226,6 +226,25 @@ def htsat_clip_label(pred_map):
     return int(np.argmax(counts))
 
 
+def htsat_classification_events(frame_predictions, events_list, class_names):
+    """src/models/htsat/classification.py:15-36: per clip of every batch the clip label (htsat_clip_label), written as
+    "event_label" into the first event of the clip's file whose "extracted_audio_filename" equals the base name of the clip's
+    path.  Works on a deep copy."""
+    import copy
+    import os
+    out = copy.deepcopy(events_list)
+    for batch in frame_predictions:
+        for i in range(len(batch["file"])):
+            filename = batch["file"][i]
+            extracted = os.path.basename(batch["file_path"][i])
+            label = class_names[htsat_clip_label(np.asarray(batch["pred_map"][i]))]
+            for ev in out[filename]:
+                if ev["extracted_audio_filename"] == extracted:
+                    ev["event_label"] = label
+                    break
+    return out
+
+
 def pack_events(runs, counts, cap, first_stream=0):
     """Event records of a stream batch as the GPUs exchange them: runs (S, C, cap_in, 2) int, counts (S, C) ->
     int32 (S, cap + 1, 4).  Row 0 of a stream = (records kept, records dropped, 0, 0); rows 1.. = (stream +

@@ -469,6 +469,35 @@ def get_classification_label(pred_map, class_names: Sequence[str] = tuple(CLASSE
     return labels[0] if single else labels
 
 
+def get_classification_events(frame_predictions, events_list, CLASS_LABELS=tuple(CLASSES + [NON_EVENT_LABEL])):
+    """src/models/htsat/classification.py:15-36 with its signature: every clip of every test batch
+    ({"file": [...], "file_path": [...], "pred_map": (B, T, C)}) gets its clip label (get_classification_label), and the
+    first event of events_list[file] whose "extracted_audio_filename" is the base name of the clip's path takes it as
+    "event_label".  events_list is updated in place and returned.  CLASS_LABELS: a sequence of names or an object with
+    int2str (datasets.ClassLabel).  One histogram launch per batch; a file that is not in events_list raises KeyError as
+    the reference does."""
+    import os
+    name_of = CLASS_LABELS.int2str if hasattr(CLASS_LABELS, "int2str") else (lambda k: CLASS_LABELS[k])
+    for batch in frame_predictions:
+        files = batch["file"]
+        if len(files) == 0:
+            continue
+        pm = batch["pred_map"]
+        if isinstance(pm, (list, tuple)):
+            pm = torch.stack([torch.as_tensor(m) for m in pm])
+        hist = argmax_histogram(_to_dev(pm, torch.float32)[:len(files)], drop_last_classes=1).cpu().numpy()
+        for i, filename in enumerate(files):
+            extracted = os.path.basename(batch["file_path"][i])
+            label = name_of(int(np.argmax(hist[i])))
+            events = events_list[filename]
+            for ev in events:
+                if ev["extracted_audio_filename"] == extracted:
+                    ev["event_label"] = label
+                    break
+            events_list[filename] = events
+    return events_list
+
+
 def _framewise_expand(x: torch.Tensor, ratio: int, frames_out: int, what: str) -> torch.Tensor:
     if not (torch.is_tensor(x) and x.is_cuda):
         raise RuntimeError(f"{what}: expected a tensor on a ROCm device (this path has no CPU implementation)")

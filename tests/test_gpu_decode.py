@@ -380,3 +380,39 @@ def test_decoded_events_scored_like_main():
         oe.evaluate(gt[n], pred[n]); osg.evaluate(gt[n], pred[n])
     assert ev.results()["overall"] == oe.results_overall_metrics() and seg.results()["overall"] == osg.results_overall_metrics()
     assert "Event based metrics (onset-offset)" in str(ev) and "Segment based metrics" in str(seg)
+
+
+def test_get_classification_events_like_the_reference_loop():
+    """get_classification_events (src/models/htsat/classification.py:15-36) with its signature: batches of clips, the
+    events of their files relabelled in place; against the restatement, for a ClassLabel-like object and a plain list."""
+    import copy
+    import sed_amd
+    rng = np.random.default_rng(77)
+    files = [f"rec_{k}.wav" for k in range(5)]
+    events = {f: [{"extracted_audio_filename": f"{f[:-4]}_{j}.00_{j + 1}.50.wav", "event_label": "unknown", "ground_truth": "siren"}
+                  for j in range(int(rng.integers(1, 6)))] for f in files}
+    events[files[0]].append(dict(events[files[0]][0]))                               # a repeated name: only the first is labelled
+    clips = [(f, ev["extracted_audio_filename"]) for f in files for ev in events[f][:4]]
+    batches = []
+    for k in range(0, len(clips), 4):
+        part = clips[k:k + 4]
+        pm = rng.random((len(part), int(rng.choice([64, 1024, 4096])), 6)).astype(np.float32)
+        pm[0, :, :5] = 0.0
+        pm[0, ::2, 3] = 1.0                                                           # a tie between two classes
+        pm[0, 1::2, 1] = 1.0
+        batches.append({"file": [f for f, _ in part], "file_path": [f"/tmp/extracted/{e}" for _, e in part],
+                        "pred_map": torch.from_numpy(pm)})
+    want = od.htsat_classification_events(batches, events, NAMES6)
+
+    class Labels:                                                                     # datasets.ClassLabel's part in it
+        def int2str(self, k):
+            return NAMES6[k]
+
+    for labels in (Labels(), NAMES6):
+        mine = copy.deepcopy(events)
+        got = sed_amd.get_classification_events(batches, mine, labels)
+        assert got is mine and got == want
+    assert any(ev["event_label"] == "unknown" for ev in want[files[0]])               # the repeated name stayed as it was
+    with pytest.raises(KeyError):
+        sed_amd.get_classification_events([{"file": ["nowhere.wav"], "file_path": ["/tmp/n_0.wav"],
+                                            "pred_map": torch.zeros(1, 8, 6)}], copy.deepcopy(events), NAMES6)

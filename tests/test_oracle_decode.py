@@ -147,3 +147,37 @@ def test_htsat_clip_label_vectors(golden_dir):
     names = ["cough", "dog_bark", "gun_shot", "siren", "car_horn", "non_event"]
     for i, rec in enumerate(exp):
         assert names[od.htsat_clip_label(inp[f"d7_{i}"])] == rec["label"], i
+
+
+def test_htsat_classification_events_vectors(golden_dir):
+    """The golden labels came out of the reference's get_classification_events (classification.py:15-36) for a file with
+    one event; here all twelve clips go through the restatement of that function in batches of three, as events of two
+    files, with a decoy event that repeats a clip's name (only the first match is labelled) and one event no clip names."""
+    exp = json.load(open(os.path.join(golden_dir, "d7_vectors.json")))
+    inp = np.load(os.path.join(golden_dir, "decode_inputs.npz"))
+    names = ["cough", "dog_bark", "gun_shot", "siren", "car_horn", "non_event"]
+    by_len = {}
+    for i in range(len(exp)):
+        by_len.setdefault(inp[f"d7_{i}"].shape[0], []).append(i)
+    events = {"a.wav": [], "b.wav": []}
+    batches = []
+    for n, idx in by_len.items():
+        for k in range(0, len(idx), 3):
+            part = idx[k:k + 3]
+            files = ["a.wav" if i % 2 == 0 else "b.wav" for i in part]
+            batches.append({"file": files, "file_path": [f"/x/y/{f[0]}_{i}.00_{i + 1}.00.wav" for f, i in zip(files, part)],
+                            "pred_map": np.stack([inp[f"d7_{i}"] for i in part])})
+            for f, i in zip(files, part):
+                events[f].append({"extracted_audio_filename": f"{f[0]}_{i}.00_{i + 1}.00.wav", "event_label": None, "k": i})
+    events["a.wav"].append({"extracted_audio_filename": "a_0.00_1.00.wav", "event_label": "decoy"})
+    events["b.wav"].append({"extracted_audio_filename": "b_99.00_100.00.wav", "event_label": None})
+    out = od.htsat_classification_events(batches, events, names)
+    seen = 0
+    for f in ("a.wav", "b.wav"):
+        for ev in out[f]:
+            if "k" in ev:
+                assert ev["event_label"] == exp[ev["k"]]["label"], ev
+                seen += 1
+    assert seen == len(exp)
+    assert out["a.wav"][-1]["event_label"] == "decoy" and out["b.wav"][-1]["event_label"] is None
+    assert events["a.wav"][0]["event_label"] is None                                  # the input is left alone
