@@ -58,6 +58,26 @@ def test_status_codes_of_bad_calls():
     assert L.lib.sed_logmel_forward(plan, x.data_ptr(), 2, 4096, 4096, y.data_ptr(), 100, s) == L.SED_ERR_BAD_ARG       # output rows overlap
     assert L.lib.sed_logmel_forward(plan, x.data_ptr(), 2, 300, 4096, y.data_ptr(), 13 * 64, s) == L.SED_ERR_SHORT_INPUT
     assert L.lib.sed_logmel_forward(plan, x.data_ptr(), 0, 4096, 4096, y.data_ptr(), 13 * 64, s) == 0                   # empty batch
+    # segments of a resident buffer, zero-padded rows and rows of their own; the image from rows of their own
+    off = torch.tensor([0, 4096], dtype=torch.int64, device=dev)
+    ln = torch.tensor([4096, 1000], dtype=torch.int32, device=dev)
+    for entry in (L.lib.sed_logmel_forward_segments, L.lib.sed_logmel_forward_segments_own):
+        assert entry(plan, x.data_ptr(), off.data_ptr(), ln.data_ptr(), 2, 4096, y.data_ptr(), 13 * 64, s) == 0
+        assert entry(plan, x.data_ptr(), None, ln.data_ptr(), 2, 4096, y.data_ptr(), 13 * 64, s) == L.SED_ERR_BAD_ARG
+        assert entry(plan, x.data_ptr(), off.data_ptr(), None, 2, 4096, y.data_ptr(), 13 * 64, s) == L.SED_ERR_BAD_ARG
+        assert entry(None, x.data_ptr(), off.data_ptr(), ln.data_ptr(), 2, 4096, y.data_ptr(), 13 * 64, s) == L.SED_ERR_BAD_ARG
+        assert entry(plan, x.data_ptr(), off.data_ptr(), ln.data_ptr(), 2, 4096, y.data_ptr(), 100, s) == L.SED_ERR_BAD_ARG
+        assert entry(plan, x.data_ptr(), off.data_ptr(), ln.data_ptr(), 0, 4096, y.data_ptr(), 13 * 64, s) == 0          # no segment
+    torch.cuda.synchronize()
+    assert not y[1, 4:].any() and y[1, :4].abs().sum() > 0                      # 1000 samples: 1 + 1000 // 320 rows of its own
+    fr = torch.tensor([13, 4], dtype=torch.int32, device=dev)
+    img = torch.empty(2, 1, 64, 16, device=dev)
+    assert L.lib.sed_htsat_wav2img_ragged(y.data_ptr(), fr.data_ptr(), 2, 13, 64, 16, 1, img.data_ptr(), s) == 0
+    assert L.lib.sed_htsat_wav2img_ragged(y.data_ptr(), None, 2, 13, 64, 16, 1, img.data_ptr(), s) == L.SED_ERR_BAD_ARG
+    assert L.lib.sed_htsat_wav2img_ragged(y.data_ptr(), fr.data_ptr(), 2, 13, 64, 12, 1, img.data_ptr(), s) == L.SED_ERR_BAD_ARG   # fewer columns than rows
+    assert L.lib.sed_htsat_wav2img_ragged(y.data_ptr(), fr.data_ptr(), 2, 13, 64, 16, 3, img.data_ptr(), s) == L.SED_ERR_BAD_ARG   # 16 % 3
+    assert L.lib.sed_htsat_wav2img_ragged(None, fr.data_ptr(), 2, 13, 64, 16, 1, img.data_ptr(), s) == L.SED_ERR_BAD_ARG
+    assert L.lib.sed_htsat_wav2img_ragged(y.data_ptr(), fr.data_ptr(), 0, 13, 64, 16, 1, img.data_ptr(), s) == 0
     # decoders
     p = torch.rand(3, 50, 2, device=dev)
     runs = torch.empty(3, 2, 8, 2, dtype=torch.int32, device=dev)
