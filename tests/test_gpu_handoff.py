@@ -254,6 +254,16 @@ def test_events_as_files_of_their_own_for_the_htsat_classifier():
     assert not torch.equal(y0[0], y[0])
     with pytest.raises(TypeError):
         sed_amd.reshape_wav2img(y, 512, 8, frames=frames.cpu())
+    none = sed_amd.logmel_of_events(fe, xd, sr, [], cap, per_file=True)                # no event at all
+    assert none[0].shape == (0, 1, fe.num_frames(cap, dev), 64) and none[1].numel() == 0 and none[2].numel() == 0
+    assert sed_amd.reshape_wav2img(none[0], 512, 8, frames=none[2]).shape == (0, 1, 512, 512)
+    # segment tables already on the device: the frame counts are formed there
+    off = torch.tensor([1000, n + 3], dtype=torch.int64, device=dev)
+    ln = torch.tensor([5000, 600000], dtype=torch.int32, device=dev)
+    yd, _, fd = fe.forward_segments(xd, off, ln, cap, own_edges=True)
+    assert fd.tolist() == [1 + 5000 // hop, 1 + cap // hop]
+    assert torch.equal(yd[0, :, :int(fd[0])], fe(xd[0:1, 1000:6000].contiguous())[0])
+    assert torch.equal(yd[1], fe(xd[1:2, 3:3 + cap].contiguous())[0])
     # Kaldi-framed and YAMNet plans have no segment mode
     with pytest.raises(ValueError):
         sed_amd.logmel_of_events(sed_amd.LogMelFrontend(sed_amd.FrontendConfig.yamnet()), xd, 16000, events[:2], 48000, per_file=True)
