@@ -6,7 +6,7 @@ from .frontend import (FrontendConfig, LogMelFrontend, LogmelFilterBank, Spectro
 from .decode import (decode_predictions, decode_probabilities, detect_onsets_offsets, detect_onsets_offsets_batch,
                      get_classification_events, get_classification_label, get_events, get_events_from_batch, interpolate, interpolate_and_pad,
                      merge_close_events, merge_close_events_batch, pad_framewise_output, predict_events, predict_events_batch, process_json_file)
-from .handoff import cut_events, cut_events_from_audio, logmel_of_events
+from .handoff import cut_events, cut_events_from_audio, fbank_of_events, logmel_of_events
 from .metrics import EventBasedMetrics, SegmentBasedMetrics, calculate_metrics
 from .resample import Resampler, resample
 from . import sharding

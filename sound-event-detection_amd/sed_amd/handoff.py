@@ -116,6 +116,26 @@ def logmel_of_events(frontend, pcm: torch.Tensor, sr, events: Sequence[Tuple[int
     return frontend.forward_segments(pcm, idx * max(pcm.stride(0), n) + a, length, cap, own_edges=bool(per_file))
 
 
+def fbank_of_events(pcm: torch.Tensor, sr, events: Sequence[Tuple[int, float, float]], melbins=128, target_length=1024,
+                    fshift=10, norm_mean=None, norm_std=None, pcm_divisor: float = 32768.0):
+    """The Audio-Mamba input of the detected events, every event as the file of its own the reference writes and reads back
+    (src/utils/cut_audio.py:13-53 + main.py:129-152; external/audio_mamba/src/dataloader.py:94-152, 219-221): cut_events
+    followed by wav2fbank(..., lengths=...).  pcm (S, L) fp32 or int16 on the device; events (stream index, start_sec,
+    end_sec).  Returns (fbank (E, target_length, melbins), lengths (E,) int32 on the device).  An event shorter than one
+    window gives the value of zero frames in every row."""
+    from . import frontend as F
+    win = int(int(round(sr)) * 25.0 * 0.001)
+    length = _event_ranges(events, sr, pcm.shape[1])[2] if len(events) else np.zeros(0, np.int64)
+    # rows as long as the longest event (its mean is that of all its samples, as the file's would be), never shorter than a window
+    cap = (max(int(length.max(initial=0)), win) + 3) // 4 * 4
+    clips, lengths = cut_events(pcm, sr, events, cap=cap, pcm_divisor=pcm_divisor)
+    if len(events) == 0:
+        return clips.new_empty((0, int(target_length), int(melbins))), lengths
+    fb = F.wav2fbank(clips, sr, melbins=melbins, target_length=target_length, fshift=fshift, norm_mean=norm_mean,
+                     norm_std=norm_std, lengths=lengths)
+    return fb, lengths
+
+
 def cut_events_from_audio(pcm: torch.Tensor, sr, filenames: Sequence[str], events_list: Dict[str, List[dict]],
                           cap: int = None, pcm_divisor: float = 32768.0):
     """events_list as the detector stage produces it ({filename: [{"event_onset", "event_offset", ...}]});

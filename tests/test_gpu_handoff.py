@@ -175,6 +175,13 @@ def test_events_handed_to_the_audio_mamba_front_end():
         near = want[:T] >= want[:T].max(-1, keepdims=True) - span
         assert np.max(np.abs(fb[e, :T] - want[:T])[near]) < 1e-3 / (2 * 4.5689974) + 1e-6, e
         assert np.allclose(fb[e, T:], want[T:], rtol=0, atol=1e-6), e     # zero frames behind the event
+    # the two calls as one
+    fb2, len2 = sed_amd.fbank_of_events(torch.from_numpy(x).to(dev), sr, events, melbins=128, target_length=256,
+                                        norm_mean=-4.2677393, norm_std=4.5689974)
+    assert torch.equal(len2, lengths) and np.array_equal(fb2.cpu().numpy(), fb)
+    short = sed_amd.fbank_of_events(torch.from_numpy(x).to(dev), sr, [events[1], events[5]], target_length=64)[0]
+    assert short.shape == (2, 64, 128) and not short.any()                # nothing but events shorter than a window
+    assert sed_amd.fbank_of_events(torch.from_numpy(x).to(dev), sr, [], target_length=64)[0].shape == (0, 64, 128)
     # without lengths the batch is what it looks like: clips of the padded length
     dense = sed_amd.wav2fbank(clips, sr, melbins=128, target_length=256)
     assert dense.shape == (len(events), 256, 128)
