@@ -323,7 +323,12 @@ def bench_server(args, world, rank, dev, dist):
                     pending.pop(0)[1].wait()
         if ev:
             ev[2].record()
-        if fused:      # the classifier front-end reads the events straight out of the resident recordings
+        if fused == "own":   # every event framed as the file of its own that stage 2 of the reference loads, and its image
+            if ev:
+                ev[3].record()
+            y, lengths, frames = sed_amd.logmel_of_events(cls_fe, x32, 32000, events, cap, per_file=True)
+            y = sed_amd.reshape_wav2img(y, 256, 4, frames=frames)
+        elif fused:    # the classifier front-end reads the events straight out of the resident recordings
             if ev:
                 ev[3].record()
             y, lengths = sed_amd.logmel_of_events(cls_fe, x32, 32000, events, cap)
@@ -367,6 +372,8 @@ def bench_server(args, world, rank, dev, dist):
         torch.cuda.synchronize()
     two_step_elapsed, (_, y2) = timed(False)
     two_step_stages = {n: sum(e[k].elapsed_time(e[k + 1]) for e in stage_ev) / len(stage_ev) for k, n in enumerate(names)}
+    own_elapsed, (_, img) = timed("own")
+    own_stages = {n: sum(e[k].elapsed_time(e[k + 1]) for e in stage_ev) / len(stage_ev) for k, n in enumerate(names)}
     elapsed, (feat, y) = timed(True)
     same_bits = bool(torch.equal(y, y2))
     names = ["detector_features_ms", "decode_exchange_ms_on_main_stream", "cut_events_ms", "classifier_features_ms"]
@@ -388,6 +395,12 @@ def bench_server(args, world, rank, dev, dist):
                        "two_step_handoff": {"ms_per_step": two_step_elapsed / args.steps * 1e3, "stage_ms": two_step_stages,
                                             "note": "cut_events into a zero-padded (events, 96000) batch, then the front-end on the batch",
                                             "same_log_mel_bits_as_fused": same_bits},
+                       "per_event_handoff": {"ms_per_step": own_elapsed / args.steps * 1e3, "stage_ms": own_stages,
+                                             "image": list(img.shape),
+                                             "note": "every event framed as a file of its own (reflect padding at its own end, its own "
+                                                     "frame count), then reshape_wav2img from each event's own rows to the 256 x 256 "
+                                                     "image: what the reference's batch-of-one second stage computes; "
+                                                     "classifier_features_ms includes the image here"},
                        "decode_stream": "side" if side is not None else "same", "forced_one_rank_collective": bool(args.force_collective),
                        "algorithmic_bytes_per_step": alg,
                        "parallelism": f"streams sharded over {world} GPU(s), all-gather of event record buffers"},
