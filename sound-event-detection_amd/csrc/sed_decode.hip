@@ -649,19 +649,29 @@ __global__ void __launch_bounds__(256) wav2img_kernel(const float* x, int T, int
   }
 }
 
+// One launch per 65535 clips (the grid's second dimension): clip b of a chunk is blockIdx.y.
+static void launch_wav2img(const float* logmel, const int32_t* frames, int64_t B, int64_t T, int64_t M, int64_t target_T,
+                           int bands, int seg, int col0, int col_step, float scale, float* img, hipStream_t stream) {
+  const int tiles = (seg + 63) / 64;
+  const size_t lds = (size_t)(64 + 6) * (M + 1) * sizeof(float);
+  for (int64_t b0 = 0; b0 < B; b0 += 65535) {
+    const int64_t nb = std::min<int64_t>(65535, B - b0);
+    hipLaunchKernelGGL(wav2img_kernel, dim3((unsigned)(tiles * bands), (unsigned)nb), dim3(256), lds, stream,
+                       logmel + b0 * T * M, (int)T, (int)M, (int)target_T, bands, seg, col0, col_step, scale,
+                       img + b0 * bands * M * seg, frames ? frames + b0 : (const int32_t*)nullptr);
+  }
+}
+
 extern "C" int sed_htsat_wav2img(const float* logmel, int64_t B, int64_t T, int64_t M, int64_t target_T,
                                  int32_t freq_ratio, float* img, void* stream) {
   if (B < 0 || T < 1 || M < 1 || M > 512 || freq_ratio < 1 || target_T < T || target_T % freq_ratio != 0)
     return SED_ERR_BAD_ARG;
-  if (B > 65535 || target_T > INT32_MAX / 2) return SED_ERR_BAD_ARG;
+  if (target_T > INT32_MAX / 2) return SED_ERR_BAD_ARG;
   if (B == 0) return SED_OK;
   if (!logmel || !img) return SED_ERR_BAD_ARG;
   const float scale = target_T > 1 ? (float)(T - 1) / (float)(target_T - 1) : 0.0f;
-  const int seg = (int)(target_T / freq_ratio), tiles = (seg + 63) / 64;
-  const size_t lds = (size_t)(64 + 6) * (M + 1) * sizeof(float);
-  hipLaunchKernelGGL(wav2img_kernel, dim3((unsigned)(tiles * freq_ratio), (unsigned)B), dim3(256), lds,
-                     (hipStream_t)stream, logmel, (int)T, (int)M, (int)target_T, (int)freq_ratio, seg, 0, seg, scale, img,
-                     (const int32_t*)nullptr);
+  const int seg = (int)(target_T / freq_ratio);
+  launch_wav2img(logmel, nullptr, B, T, M, target_T, (int)freq_ratio, seg, 0, seg, scale, img, (hipStream_t)stream);
   return hip_status(hipGetLastError());
 }
 
@@ -669,30 +679,24 @@ extern "C" int sed_htsat_wav2img_ragged(const float* logmel, const int32_t* fram
                                         int64_t target_T, int32_t freq_ratio, float* img, void* stream) {
   if (B < 0 || T < 1 || M < 1 || M > 512 || freq_ratio < 1 || target_T < T || target_T % freq_ratio != 0)
     return SED_ERR_BAD_ARG;
-  if (B > 65535 || target_T > INT32_MAX / 2) return SED_ERR_BAD_ARG;
+  if (target_T > INT32_MAX / 2) return SED_ERR_BAD_ARG;
   if (B == 0) return SED_OK;
   if (!logmel || !img || !frames) return SED_ERR_BAD_ARG;
-  const int seg = (int)(target_T / freq_ratio), tiles = (seg + 63) / 64;
-  const size_t lds = (size_t)(64 + 6) * (M + 1) * sizeof(float);
-  hipLaunchKernelGGL(wav2img_kernel, dim3((unsigned)(tiles * freq_ratio), (unsigned)B), dim3(256), lds,
-                     (hipStream_t)stream, logmel, (int)T, (int)M, (int)target_T, (int)freq_ratio, seg, 0, seg, 0.0f, img,
-                     frames);
+  const int seg = (int)(target_T / freq_ratio);
+  launch_wav2img(logmel, frames, B, T, M, target_T, (int)freq_ratio, seg, 0, seg, 0.0f, img, (hipStream_t)stream);
   return hip_status(hipGetLastError());
 }
 
 extern "C" int sed_htsat_repeat2img(const float* logmel, int64_t B, int64_t T, int64_t M, int64_t target_T,
                                     int64_t spec_size, int64_t cur_pos, int32_t repeats, float* img, void* stream) {
   if (B < 0 || T < 1 || M < 1 || M > 512 || repeats < 1 || target_T < T || spec_size < 1) return SED_ERR_BAD_ARG;
-  if (B > 65535 || target_T > INT32_MAX / 2) return SED_ERR_BAD_ARG;
+  if (target_T > INT32_MAX / 2) return SED_ERR_BAD_ARG;
   if (cur_pos < 0 || cur_pos + spec_size > target_T) return SED_ERR_BAD_ARG;
   if (B == 0) return SED_OK;
   if (!logmel || !img) return SED_ERR_BAD_ARG;
   const float scale = target_T > 1 ? (float)(T - 1) / (float)(target_T - 1) : 0.0f;
-  const int tiles = (int)((spec_size + 63) / 64);
-  const size_t lds = (size_t)(64 + 6) * (M + 1) * sizeof(float);
-  hipLaunchKernelGGL(wav2img_kernel, dim3((unsigned)(tiles * repeats), (unsigned)B), dim3(256), lds,
-                     (hipStream_t)stream, logmel, (int)T, (int)M, (int)target_T, (int)repeats, (int)spec_size,
-                     (int)cur_pos, 0, scale, img, (const int32_t*)nullptr);
+  launch_wav2img(logmel, nullptr, B, T, M, target_T, (int)repeats, (int)spec_size, (int)cur_pos, 0, scale, img,
+                 (hipStream_t)stream);
   return hip_status(hipGetLastError());
 }
 

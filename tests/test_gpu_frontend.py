@@ -595,3 +595,28 @@ def test_random_htsat_style_configurations():
         assert got.shape == gold.shape == (B, 1 + n // hop, n_mels), (case, sr, n_fft, hop, n_mels)
         print(case, sr, n_fft, hop, n_mels, fmin, round(fmax, 1), n, end=": ")
         _check(got, gold, ref32, NEAR_DB)
+
+
+def test_image_builders_beyond_one_launch_of_clips():
+    """More clips than one launch holds in its grid (65535): the image builders go on in further launches; clips on either
+    side of the boundary against the same call on that clip alone."""
+    import sed_amd
+    dev = _dev()
+    B, T, F, spec, ratio = 70000, 9, 16, 16, 1
+    g = torch.Generator(device=dev).manual_seed(3)
+    x = torch.randn((B, 1, T, F), generator=g, device=dev) * 20 - 40
+    frames = torch.randint(0, T + 1, (B,), generator=g, device=dev, dtype=torch.int32)
+    dense = sed_amd.reshape_wav2img(x, spec, ratio)
+    ragged = sed_amd.reshape_wav2img(x, spec, ratio, frames=frames)
+    assert dense.shape == ragged.shape == (B, 1, spec, spec)
+    for b in (0, 65534, 65535, 65536, B - 1):
+        assert torch.equal(dense[b:b + 1], sed_amd.reshape_wav2img(x[b:b + 1].contiguous(), spec, ratio)), b
+        n = int(frames[b])
+        if n:
+            assert torch.equal(ragged[b:b + 1], sed_amd.reshape_wav2img(x[b:b + 1, :, :n].contiguous(), spec, ratio)), b
+        else:
+            assert not ragged[b].any()
+    x4 = x[:, :, :, :4].contiguous()                                  # 4 mel bins, spec 16, ratio 4: 64 frames, windows of 16
+    rep = sed_amd.repeat_wat2img(x4, 5, 16, 4)
+    for b in (65534, 65535, B - 1):
+        assert torch.equal(rep[b:b + 1], sed_amd.repeat_wat2img(x4[b:b + 1].contiguous(), 5, 16, 4)), b
