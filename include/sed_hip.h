@@ -148,7 +148,8 @@ int sed_logmel_forward(const sed_plan* plan, const void* pcm, int64_t B, int64_t
  * zero-padded batch sed_cut_events would write with cap = L, and the result equals sed_logmel_forward on that batch bit for
  * bit.  seg_off int64 [n_segments] and seg_len int32 [n_segments] are DEVICE arrays; 0 <= seg_len[e] <= L, and every
  * segment must lie inside the buffer (not checked: the arrays are not read on the host).  out fp32 [n_segments][T][n_mels],
- * T = sed_plan_num_frames(plan, L).  Plans with a YAMNet tail or per-frame conditioning return SED_ERR_BAD_ARG. */
+ * T = sed_plan_num_frames(plan, L).  Plans with per-frame conditioning (the Kaldi filterbank) are served; plans with a
+ * YAMNet tail return SED_ERR_BAD_ARG. */
 int sed_logmel_forward_segments(const sed_plan* plan, const void* pcm, const int64_t* seg_off, const int32_t* seg_len,
                                 int64_t n_segments, int64_t L, float* out, int64_t out_stride_b, void* stream);
 

@@ -64,3 +64,17 @@ for secs in (3.0, 1.5, 0.5):
     ti = timed(lambda: sed_amd.reshape_wav2img(y, 256, 4, frames=frames))
     td = timed(lambda: sed_amd.reshape_wav2img(y, 256, 4))
     print(f"events as files of their own, {secs} s: {tk:.1f} us (kernel + frame counts), image from own rows {ti:.1f} us (dense image {td:.1f} us)")
+
+# the Audio-Mamba hand-off at the rate of the reference's files: Kaldi filterbank of 1024 events (0.5 .. 3 s) out of 128
+# recordings of 10 s at 44.1 kHz, the filterbank kernel reading the events in place against cut + wav2fbank
+sr44, S44 = 44100, 128
+x44 = (0.1 * torch.randn((S44, 10 * sr44), device=dev)).contiguous()
+ev44 = []
+for e in range(1024):
+    secs = float(rng.uniform(0.5, 3.0))
+    a = float(rng.uniform(0.0, 10.0 - secs))
+    ev44.append((e % S44, a, a + secs))
+for fused in (True, False):
+    t = timed(lambda: sed_amd.fbank_of_events(x44, sr44, ev44, melbins=128, target_length=1024, norm_mean=-4.27, norm_std=4.57,
+                                              fused=fused), reps=20)
+    print(f"Audio-Mamba input of 1024 events (0.5 .. 3 s) at 44.1 kHz, {'filterbank kernel on the events in place' if fused else 'cut + wav2fbank'}: {t:.0f} us")

@@ -1438,10 +1438,10 @@ static int launch_front_shape(const sed_plan* pl, FrontParams p, int64_t B, hipS
 #else
   auto kern = (p.pcm_kind & ~kPcmDiv3) == SED_PCM_I16 ? stft_mel_kernel<G, MAG, SPEC_OUT, PRE, true, Mel>
                                                        : stft_mel_kernel<G, MAG, SPEC_OUT, PRE, false, Mel>;
-  if (p.seg_off) {  // clips are segments of a resident buffer: built for the fused log-mel kernels without per-frame conditioning
-    if constexpr (SPEC_OUT || PRE) return SED_ERR_BAD_ARG;
-    else kern = (p.pcm_kind & ~kPcmDiv3) == SED_PCM_I16 ? stft_mel_kernel<G, MAG, false, false, true, Mel, true>
-                                                         : stft_mel_kernel<G, MAG, false, false, false, Mel, true>;
+  if (p.seg_off) {  // clips are segments of a resident buffer: built for the fused log-mel kernels
+    if constexpr (SPEC_OUT) return SED_ERR_BAD_ARG;
+    else kern = (p.pcm_kind & ~kPcmDiv3) == SED_PCM_I16 ? stft_mel_kernel<G, MAG, false, PRE, true, Mel, true>
+                                                         : stft_mel_kernel<G, MAG, false, PRE, false, Mel, true>;
   }
 #endif
   // the dynamic LDS limit is a property of the kernel function, set once per instantiation (per device: the attribute
@@ -1649,7 +1649,7 @@ extern "C" int sed_logmel_forward(const sed_plan* pl, const void* pcm, int64_t B
 extern "C" int sed_logmel_forward_segments(const sed_plan* pl, const void* pcm, const int64_t* seg_off, const int32_t* seg_len,
                                            int64_t n_segments, int64_t L, float* out, int64_t out_stride_b, void* stream) {
   if (!seg_off || !seg_len) return SED_ERR_BAD_ARG;
-  if (pl && (pl->cfg.tail_min_samples > 0 || pl->cfg.remove_dc || pl->cfg.preemphasis > 0.0f)) return SED_ERR_BAD_ARG;
+  if (pl && pl->cfg.tail_min_samples > 0) return SED_ERR_BAD_ARG;
   return front_forward<false>(pl, pcm, n_segments, L, L, out, out_stride_b, stream, seg_off, seg_len);
 }
 
@@ -1657,7 +1657,7 @@ extern "C" int sed_logmel_forward_segments_own(const sed_plan* pl, const void* p
                                                const int32_t* seg_len, int64_t n_segments, int64_t L, float* out,
                                                int64_t out_stride_b, void* stream) {
   if (!seg_off || !seg_len) return SED_ERR_BAD_ARG;
-  if (pl && (pl->cfg.tail_min_samples > 0 || pl->cfg.remove_dc || pl->cfg.preemphasis > 0.0f)) return SED_ERR_BAD_ARG;
+  if (pl && pl->cfg.tail_min_samples > 0) return SED_ERR_BAD_ARG;
   return front_forward<false>(pl, pcm, n_segments, L, L, out, out_stride_b, stream, seg_off, seg_len, true);
 }
 

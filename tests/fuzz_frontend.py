@@ -226,7 +226,33 @@ def kaldi_case(rng, case):
         gold = of.kaldi_fbank(x, sr, mel, frame_length, frame_shift, mode="gold")
         ref32 = of.kaldi_fbank(x, sr, mel, frame_length, frame_shift, mode="ref32")
         near, deep = check(got, gold, ref32, NEAR_DB / 10.0 * np.log(10.0), deep_factor=2.5, per_unit=1.0)
-        print(f"ok   {desc} near {near:.1e} deep {deep:.1e}", flush=True)
+        # segment mode of the Kaldi-framed kernels: events out of the resident batch, as a zero-padded batch (against cut +
+        # front-end) and as files of their own (against the front-end on each event alone), both bit for bit
+        dev = torch.device("cuda", 0)
+        xt = torch.from_numpy(x).to(dev)
+        fe = sed_amd.LogMelFrontend(sed_amd.FrontendConfig.kaldi_fbank(sr, mel, frame_length, frame_shift), layout="btm")
+        win, hop = fe.cfg.win_length, fe.cfg.hop
+        events = []
+        for _ in range(int(rng.integers(1, 6))):
+            a = float(rng.uniform(0, (n - win) / sr))
+            events.append((int(rng.integers(B)), a, a + float(rng.uniform(win / sr, n / sr - a))))
+        events.append((0, 0.0, (win - 1) / sr))                          # one sample short of a frame
+        events.append((B - 1, 0.001, 0.001 + (win + 0.5) / sr))         # exactly one frame
+        cap = int(rng.integers(win, n + 1))
+        clips, lengths = sed_amd.cut_events(xt, sr, events, cap)[:2]
+        seg, glen = sed_amd.logmel_of_events(fe, xt, sr, events, cap)
+        assert torch.equal(glen.cpu(), lengths.cpu()), "segment lengths"
+        assert torch.equal(seg, fe(clips)), f"segment mode differs from cut + front-end (max {float(torch.max(torch.abs(seg - fe(clips)))):.3e})"
+        own, _, frames = sed_amd.logmel_of_events(fe, xt, sr, events, cap, per_file=True)
+        for e, (s_, a, b) in enumerate(events):
+            piece = x[s_, int(a * sr):int(b * sr)][:cap]
+            Te = 1 + (len(piece) - win) // hop if len(piece) >= win else 0
+            assert int(frames[e]) == Te, f"own frames of event {e}: {int(frames[e])} for {Te}"
+            assert not own[e, Te:].any(), f"rows behind event {e}"
+            if Te:
+                alone = fe(torch.from_numpy(piece[None].copy()).to(dev))
+                assert torch.equal(own[e, :Te], alone[0]), f"event {e} of {len(piece)} samples differs from the event alone"
+        print(f"ok   {desc} near {near:.1e} deep {deep:.1e} seg{len(events)}", flush=True)
         return True
     except Exception as e:  # noqa: BLE001
         print(f"FAIL {desc}: {type(e).__name__}: {e}", flush=True)
@@ -240,8 +266,9 @@ def main():
     dev = torch.device("cuda", 0)
     rng = np.random.default_rng(seed)
     bad = 0
+    only_kaldi = len(sys.argv) > 3 and sys.argv[3] == "kaldi"                 # python3 tests/fuzz_frontend.py 100 7 kaldi
     for case in range(cases):
-        ok = kaldi_case(rng, case) if case % 8 == 7 else functions_case(rng, case, dev) if case % 8 == 3 else one_case(rng, case, dev)
+        ok = kaldi_case(rng, case) if case % 8 == 7 or only_kaldi else functions_case(rng, case, dev) if case % 8 == 3 else one_case(rng, case, dev)
         bad += not ok
     print(f"{cases - bad} of {cases} cases passed")
     sys.exit(1 if bad else 0)

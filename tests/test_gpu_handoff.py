@@ -175,13 +175,37 @@ def test_events_handed_to_the_audio_mamba_front_end():
         near = want[:T] >= want[:T].max(-1, keepdims=True) - span
         assert np.max(np.abs(fb[e, :T] - want[:T])[near]) < 1e-3 / (2 * 4.5689974) + 1e-6, e
         assert np.allclose(fb[e, T:], want[T:], rtol=0, atol=1e-6), e     # zero frames behind the event
-    # the two calls as one
-    fb2, len2 = sed_amd.fbank_of_events(torch.from_numpy(x).to(dev), sr, events, melbins=128, target_length=256,
-                                        norm_mean=-4.2677393, norm_std=4.5689974)
+    # the two calls as one, and the fused form (the filterbank kernel reads the events out of the recordings)
+    xd = torch.from_numpy(x).to(dev)
+    fb2, len2 = sed_amd.fbank_of_events(xd, sr, events, melbins=128, target_length=256, norm_mean=-4.2677393,
+                                        norm_std=4.5689974, fused=False)
     assert torch.equal(len2, lengths) and np.array_equal(fb2.cpu().numpy(), fb)
-    short = sed_amd.fbank_of_events(torch.from_numpy(x).to(dev), sr, [events[1], events[5]], target_length=64)[0]
-    assert short.shape == (2, 64, 128) and not short.any()                # nothing but events shorter than a window
-    assert sed_amd.fbank_of_events(torch.from_numpy(x).to(dev), sr, [], target_length=64)[0].shape == (0, 64, 128)
+    fb3, len3 = sed_amd.fbank_of_events(xd, sr, events, melbins=128, target_length=256, norm_mean=-4.2677393, norm_std=4.5689974)
+    assert torch.equal(len3, lengths) and fb3.shape == fb2.shape
+    fb3 = fb3.cpu().numpy()
+    worst = 0.0
+    for e, (s, a, b) in enumerate(events):
+        piece = x[s, int(a * sr):int(b * sr)]
+        if len(piece) < win:
+            assert np.allclose(fb3[e], pad_value, rtol=0, atol=1e-6)
+            continue
+        want = of.aum_wav2fbank(piece[None], sr, 128, 256, 10, -4.2677393, 4.5689974, mode="gold")[0]
+        T = min(256, 1 + (len(piece) - win) // hop)
+        near = want[:T] >= want[:T].max(-1, keepdims=True) - span
+        assert np.max(np.abs(fb3[e, :T] - want[:T])[near]) < 1e-3 / (2 * 4.5689974) + 1e-6, e
+        assert np.allclose(fb3[e, T:], want[T:], rtol=0, atol=1e-6), e
+        worst = max(worst, float(np.max(np.abs(fb3[e, :T] - fb[e, :T])[near])) * 2 * 4.5689974)
+    assert worst < 1e-4, worst                                            # fused against cut + wav2fbank, in nepers (measured 2.3e-5)
+    for fused in (True, False):
+        short = sed_amd.fbank_of_events(xd, sr, [events[1], events[5]], target_length=64, fused=fused)[0]
+        assert short.shape == (2, 64, 128) and not short.any()            # nothing but events shorter than a window
+        assert sed_amd.fbank_of_events(xd, sr, [], target_length=64, fused=fused)[0].shape == (0, 64, 128)
+    # int16 recordings, as the wav files hold them
+    xi = torch.from_numpy(of.f32_to_pcm16(x)).to(dev)
+    f16a = sed_amd.fbank_of_events(xi, sr, events, target_length=256)[0]
+    f16b = sed_amd.fbank_of_events(xi, sr, events, target_length=256, fused=False)[0]
+    live = f16b > f16b.amax(dim=-1, keepdim=True) - 60.0 / 10.0 * np.log(10.0)
+    assert float((f16a - f16b).abs()[live].max()) < 1e-4
     # without lengths the batch is what it looks like: clips of the padded length
     dense = sed_amd.wav2fbank(clips, sr, melbins=128, target_length=256)
     assert dense.shape == (len(events), 256, 128)
@@ -271,7 +295,7 @@ def test_events_as_files_of_their_own_for_the_htsat_classifier():
     assert fd.tolist() == [1 + 5000 // hop, 1 + cap // hop]
     assert torch.equal(yd[0, :, :int(fd[0])], fe(xd[0:1, 1000:6000].contiguous())[0])
     assert torch.equal(yd[1], fe(xd[1:2, 3:3 + cap].contiguous())[0])
-    # Kaldi-framed and YAMNet plans have no segment mode
+    # plans with the YAMNet tail have no segment mode
     with pytest.raises(ValueError):
         sed_amd.logmel_of_events(sed_amd.LogMelFrontend(sed_amd.FrontendConfig.yamnet()), xd, 16000, events[:2], 48000, per_file=True)
 
