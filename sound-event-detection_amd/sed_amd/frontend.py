@@ -511,7 +511,8 @@ class LogMelFrontend(_PlanHolder):
         return out
 
     @torch.no_grad()
-    def forward_segments(self, pcm: torch.Tensor, seg_off, seg_len, n_samples: int, own_edges: bool = False):
+    def forward_segments(self, pcm: torch.Tensor, seg_off, seg_len, n_samples: int, own_edges: bool = False,
+                         out: torch.Tensor = None):
         """Log-mel of segments of a resident PCM buffer (the hand-off of handoff.logmel_of_events): clip e is the seg_len[e]
         samples from ELEMENT seg_off[e] of pcm's storage on, zero-padded to n_samples.  seg_off / seg_len: integer sequences
         or arrays on the host (checked against the buffer, clamped to n_samples and uploaded in one asynchronous copy), or
@@ -523,7 +524,10 @@ class LogMelFrontend(_PlanHolder):
         STFT's padding rule applies at the segment's own end and the segment has its own number of frames.  Returns
         (log-mel, lengths, frames): frames (E,) int32 on the device, rows [0, frames[e]) of clip e hold its log-mel (the
         values the front-end gives for those samples alone) and the rows behind them are zero.  A segment too short for one
-        frame has frames[e] = 0."""
+        frame has frames[e] = 0.
+
+        out (layout "btm" only): a contiguous fp32 (E, rows >= frames of n_samples, n_mels) tensor on pcm's device whose
+        clip slots the kernel writes in place; the returned log-mel is the view out[:, :frames of n_samples]."""
         _require_cuda(pcm, "LogMelFrontend.forward_segments")
         want = torch.int16 if self.cfg.pcm_kind == L.PCM_I16 else torch.float32
         if pcm.dtype != want:
@@ -563,7 +567,15 @@ class LogMelFrontend(_PlanHolder):
             d_off, d_len = d_stage[:8 * E].view(torch.int64), d_stage[8 * E:12 * E].view(torch.int32)
             lengths = d_stage[12 * E:16 * E].view(torch.int32)
             frames = d_stage[16 * E:20 * E].view(torch.int32)
-        out = torch.empty((E, T, self.cfg.n_mels), dtype=torch.float32, device=pcm.device)
+        if out is None:
+            out = torch.empty((E, T, self.cfg.n_mels), dtype=torch.float32, device=pcm.device)
+        else:
+            if self.layout != "btm":
+                raise ValueError("forward_segments(out=...) is for the (clips, frames, mel) layout")
+            if not (torch.is_tensor(out) and out.device == pcm.device and out.dtype == torch.float32 and out.dim() == 3 and
+                    out.shape[0] == E and out.shape[1] >= T and out.shape[2] == self.cfg.n_mels and out.is_contiguous()):
+                raise ValueError(f"out: a contiguous fp32 ({E}, >= {T}, {self.cfg.n_mels}) tensor on pcm's device")
+        rows = out.shape[1]
         if own_edges:
             entry, name = L.lib.sed_logmel_forward_segments_own, "sed_logmel_forward_segments_own"
         else:
@@ -571,7 +583,8 @@ class LogMelFrontend(_PlanHolder):
         if E and T:
             with torch.cuda.device(pcm.device):
                 L.check(entry(plan.ptr, pcm.data_ptr(), d_off.data_ptr(), d_len.data_ptr(), E, n_samples, out.data_ptr(),
-                              T * self.cfg.n_mels, L.stream_ptr(pcm.device)), name)
+                              rows * self.cfg.n_mels, L.stream_ptr(pcm.device)), name)
+        out = out[:, :T]
         if self.layout == "b1tm":
             out = out[:, None, :, :]
         elif self.layout == "bmt":

@@ -162,13 +162,16 @@ def fbank_of_events(pcm: torch.Tensor, sr, events: Sequence[Tuple[int, float, fl
         raise ValueError("event names a stream outside the batch")
     # rows: the samples target_length frames read, or the longest event if that is shorter; never shorter than a window
     cap = max(win, min(win + (int(target_length) - 1) * hop, int(length.max(initial=0))))
-    fb, lengths, _ = fe.forward_segments(pcm, idx * max(pcm.stride(0), n) + a, length, cap, own_edges=True)
-    if fb.shape[1] < target_length:
-        fb = torch.nn.functional.pad(fb, (0, 0, 0, int(target_length) - fb.shape[1]))
-    else:
-        fb = fb[:, :int(target_length)]
+    # the kernel writes into the (E, target_length, melbins) result; only the rows it wrote are normalised, the zero frames
+    # behind them are filled with the value the same arithmetic gives a zero
+    fb = torch.empty((E, int(target_length), int(melbins)), dtype=torch.float32, device=pcm.device)
+    head, lengths, _ = fe.forward_segments(pcm, idx * max(pcm.stride(0), n) + a, length, cap, own_edges=True, out=fb)
+    fill = torch.zeros((), dtype=torch.float32, device=pcm.device)
     if norm_mean is not None and norm_std is not None:
-        fb = (fb - norm_mean) / (norm_std * 2)
+        head.sub_(norm_mean).div_(norm_std * 2)
+        fill = (fill - norm_mean) / (norm_std * 2)
+    if head.shape[1] < fb.shape[1]:
+        fb[:, head.shape[1]:] = fill
     return fb, lengths
 
 
