@@ -77,8 +77,8 @@ struct FrontParams {
   // segment mode (SEG kernels): clip b is seg_len[b] samples starting at element seg_off[b] of pcm, followed by zeros up to L
   const int64_t* seg_off;
   const int32_t* seg_len;
-  // seg_own: every segment is framed as a recording of its own length (padding rule at its own end, only its own frames
-  // written): a segment of n samples has 0 frames if n < own_min, else 1 + (n - own_sub) / hop
+  // seg_own: every segment is framed as a recording of its own length (padding rule at its own end, zero rows behind its
+  // own frames): a segment of n samples has 0 frames if n < own_min, else 1 + (n - own_sub) / hop
   int32_t seg_own, own_min, own_sub;
   unsigned long long* stamps;  // SED_TIMELINE builds only
 };
