@@ -224,19 +224,25 @@ class _PlanHolder(nn.Module):
         return ent[0]
 
 
-def _run_front(plan: _Plan, x: torch.Tensor, spectrogram: bool) -> torch.Tensor:
+def _run_front(plan: _Plan, x: torch.Tensor, spectrogram: bool, out: torch.Tensor = None) -> torch.Tensor:
+    """out: a contiguous fp32 (B, rows >= T, row) tensor whose clip slots the kernel writes in place; the view out[:, :T] is
+    returned."""
     cfg = plan.cfg
     B, n = x.shape
     T = plan.num_frames(n)
     row = cfg.n_bins if spectrogram else cfg.n_mels
-    out = torch.empty((B, T, row), dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty((B, T, row), dtype=torch.float32, device=x.device)
+    elif not (out.device == x.device and out.dtype == torch.float32 and out.dim() == 3 and out.shape[0] == B and
+              out.shape[1] >= T and out.shape[2] == row and out.is_contiguous()):
+        raise ValueError(f"out: a contiguous fp32 ({B}, >= {T}, {row}) tensor on the input's device")
     if B == 0 or T == 0:
-        return out
+        return out[:, :T]
     fn = L.lib.sed_spectrogram_forward if spectrogram else L.lib.sed_logmel_forward
     with torch.cuda.device(x.device):
-        L.check(fn(plan.ptr, x.data_ptr(), B, n, max(x.stride(0), n), out.data_ptr(), T * row, L.stream_ptr(x.device)),
-                "sed_spectrogram_forward" if spectrogram else "sed_logmel_forward")
-    return out
+        L.check(fn(plan.ptr, x.data_ptr(), B, n, max(x.stride(0), n), out.data_ptr(), out.shape[1] * row,
+                   L.stream_ptr(x.device)), "sed_spectrogram_forward" if spectrogram else "sed_logmel_forward")
+    return out[:, :T]
 
 
 class _ConvWeight(nn.Module):
@@ -710,21 +716,27 @@ def wav2fbank(waveform, sr, melbins=128, target_length=1024, fshift=10, norm_mea
         inside = torch.arange(x.shape[1], device=x.device)[None, :] < n_valid[:, None]
         x = torch.where(inside, x, torch.zeros((), dtype=x.dtype, device=x.device))
         x = x - x.sum(dim=1, keepdim=True) / n_valid.clamp(min=1)[:, None].to(x.dtype)
-    fb = kaldi_fbank(x, sample_frequency=sr, num_mel_bins=melbins, frame_shift=fshift, htk_compat=True)
-    if fb.dim() == 2:
-        fb = fb[None]
-    if lengths is not None:
-        win, hop = int(int(round(sr)) * 25.0 * 0.001), int(int(round(sr)) * fshift * 0.001)
-        frames = torch.where(n_valid >= win, 1 + (n_valid - win) // hop, torch.zeros_like(n_valid))
-        keep = torch.arange(fb.shape[1], device=x.device)[None, :] < frames[:, None]
-        fb = torch.where(keep[:, :, None], fb, torch.zeros((), dtype=fb.dtype, device=fb.device))
-    n = fb.shape[1]
-    if n < target_length:
-        fb = torch.nn.functional.pad(fb, (0, 0, 0, target_length - n))
+    cfg = FrontendConfig.kaldi_fbank(sr, melbins, 25.0, fshift)
+    plan = _functional(cfg, "btm")._plan_for(x.device)
+    B, target_length = x.shape[0], int(target_length)
+    T = plan.num_frames(x.shape[1]) if x.shape[1] >= cfg.win_length else 0
+    if T <= target_length:
+        # the kernel writes into the result; only the rows it wrote are masked and normalised, the zero frames behind them
+        # are filled with the value the same arithmetic gives a zero
+        fb = torch.empty((B, target_length, int(melbins)), dtype=torch.float32, device=x.device)
+        head = _run_front(plan, x, spectrogram=False, out=fb) if T else fb[:, :0]
     else:
-        fb = fb[:, :target_length]
+        fb = head = _run_front(plan, x, spectrogram=False)[:, :target_length]
+    if lengths is not None and head.shape[1]:
+        frames = torch.where(n_valid >= cfg.win_length, 1 + (n_valid - cfg.win_length) // cfg.hop, torch.zeros_like(n_valid))
+        gone = torch.arange(head.shape[1], device=x.device)[None, :] >= frames[:, None]
+        head.masked_fill_(gone[:, :, None], 0.0)
+    fill = torch.zeros((), dtype=torch.float32, device=x.device)
     if norm_mean is not None and norm_std is not None:
-        fb = (fb - norm_mean) / (norm_std * 2)
+        head.sub_(norm_mean).div_(norm_std * 2)
+        fill = (fill - norm_mean) / (norm_std * 2)
+    if head.shape[1] < fb.shape[1]:
+        fb[:, head.shape[1]:] = fill
     return fb
 
 
